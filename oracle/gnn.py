@@ -1,0 +1,186 @@
+"""Patch-graph GNN (GraphMIL), restated on torch-CPU (oracle / test infrastructure).
+
+Follows ``GraphMIL`` in `05_train_gnns.py:51-219` and the graph train step of
+`05_train_gnns.py:336-346`.
+
+PARITY UNPINNED for the message-passing layers: the reference calls
+``torch_geometric.nn.GCNConv`` / ``GCN2Conv`` (`05_train_gnns.py:82,109`) and
+``torch_geometric`` is neither vendored nor version-pinned, and is absent here.
+``gcn_conv`` / ``gcn2_conv`` restate PyG's published layer definitions:
+  GCNConv : x' = x W^T (no bias in lin); add *remaining* self loops (w=1);
+            deg[i] = sum_{e: dst=i} w_e ; w^ = deg^-1/2[src] * w * deg^-1/2[dst];
+            out[i] = sum_{e: dst=i} w^_e x'[src_e] ; out += bias
+  GCN2Conv: beta = log(theta/layer + 1); h = (1-alpha) * A^ x + alpha * x_0;
+            out = (1-beta) * h + beta * (h @ weight1)
+The ``mlp`` graph model is pure torch in the reference and IS pinned by
+``tests/golden/graphmil_mlp_*.npz``.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import mil as _mil
+
+
+def add_remaining_self_loops(edge_index, edge_weight, n):
+    """Drop existing self loops, append one loop per node; a node's existing
+    loop weight is kept, otherwise 1 (PyG ``add_remaining_self_loops``)."""
+    row, col = edge_index[0], edge_index[1]
+    keep = row != col
+    loop_w = torch.ones(n, dtype=edge_weight.dtype)
+    if (~keep).any():
+        loop_w[row[~keep]] = edge_weight[~keep]
+    loops = torch.arange(n, dtype=edge_index.dtype)
+    ei = torch.cat([edge_index[:, keep], torch.stack([loops, loops])], dim=1)
+    ew = torch.cat([edge_weight[keep], loop_w])
+    return ei, ew
+
+
+def gcn_norm(edge_index, edge_weight, n, dtype=torch.float32):
+    if edge_weight is None:
+        edge_weight = torch.ones(edge_index.size(1), dtype=dtype)
+    ei, ew = add_remaining_self_loops(edge_index, edge_weight, n)
+    row, col = ei[0], ei[1]
+    deg = torch.zeros(n, dtype=ew.dtype).index_add_(0, col, ew)
+    dis = deg.pow(-0.5)
+    dis[torch.isinf(dis)] = 0.0
+    return ei, dis[row] * ew * dis[col]
+
+
+def propagate(x, ei, w):
+    """out[dst] += w * x[src]  (flow = source_to_target)."""
+    out = torch.zeros_like(x)
+    return out.index_add_(0, ei[1], x[ei[0]] * w.unsqueeze(1))
+
+
+def gcn_conv(x, edge_index, edge_weight, lin_weight, bias):
+    ei, w = gcn_norm(edge_index, edge_weight, x.size(0), x.dtype)
+    return propagate(F.linear(x, lin_weight), ei, w) + bias
+
+
+def gcn2_conv(x, x0, edge_index, edge_weight, weight1, alpha, theta, layer):
+    beta = math.log(theta / layer + 1.0)
+    ei, w = gcn_norm(edge_index, edge_weight, x.size(0), x.dtype)
+    h = propagate(x, ei, w) * (1.0 - alpha) + alpha * x0
+    return (1.0 - beta) * h + beta * (h @ weight1)
+
+
+DEFAULT_CFG = dict(  # the 05 call site, `05_train_gnns.py:310-326`
+    gnn_type="gcn", gnn_hidden=128, gnn_layers=2, gnn_dropout=0.5, gnn_heads=4,
+    gnn_concat=True, gcnii_alpha=0.1, gcnii_theta=0.5, att_dim=128, att_heads=4,
+    pool_dropout=0.2, classifier_dim=128, classifier_light=True, num_classes=7,
+    use_residual=True, use_layer_norm=True,
+)
+
+
+def graphmil_shapes(input_dim, cfg):
+    """Parameter names/shapes as ``GraphMIL.__init__`` creates them
+    (`05_train_gnns.py:52-154`), for the gnn types the oracle restates."""
+    from collections import OrderedDict
+    c = dict(DEFAULT_CFG, **cfg)
+    F_, t = c["gnn_hidden"], c["gnn_type"]
+    s = OrderedDict()
+    has_proj = (c["use_residual"] or t in ("fagcn", "gcnii")) and input_dim != F_
+    if has_proj:
+        s["input_proj.weight"] = (F_, input_dim)
+        s["input_proj.bias"] = (F_,)
+    in_dim = F_ if has_proj else input_dim
+    for i in range(c["gnn_layers"]):
+        if t == "gcn":  # PyG GCNConv: bias, lin.weight
+            s[f"gnn_layers.{i}.bias"] = (F_,)
+            s[f"gnn_layers.{i}.lin.weight"] = (F_, in_dim)
+        elif t == "gcnii":
+            s[f"gnn_layers.{i}.weight1"] = (F_, F_)
+        elif t == "mlp":
+            s[f"gnn_layers.{i}.0.weight"] = (F_, in_dim)
+            s[f"gnn_layers.{i}.0.bias"] = (F_,)
+        else:
+            raise ValueError(f"Unsupported gnn_type: {t}")
+        in_dim = F_
+    if c["use_layer_norm"]:
+        for i in range(c["gnn_layers"]):
+            s[f"layer_norms.{i}.weight"] = (F_,)
+            s[f"layer_norms.{i}.bias"] = (F_,)
+    for h in range(c["att_heads"]):
+        s[f"attention_layers.{h}.0.weight"] = (c["att_dim"], F_)
+        s[f"attention_layers.{h}.0.bias"] = (c["att_dim"],)
+        s[f"attention_layers.{h}.2.weight"] = (1, c["att_dim"])
+        s[f"attention_layers.{h}.2.bias"] = (1,)
+    cd = c["classifier_dim"]
+    if c["classifier_light"]:
+        s["classifier.0.weight"] = (cd, F_)
+        s["classifier.0.bias"] = (cd,)
+        s["classifier.3.weight"] = (c["num_classes"], cd)
+        s["classifier.3.bias"] = (c["num_classes"],)
+    else:
+        raise ValueError("oracle restates the light classifier only (05 call site, 05:321)")
+    return s
+
+
+def graphmil_forward(p, cfg, x, edge_index=None, edge_weight=None, drop=None):
+    """`05_train_gnns.py:156-219`.  Returns dict(probs, att, hs, z, logits).
+
+    ``drop`` = dict(seed, stream_base) enables counter-based dropout in train
+    mode: GNN layer i uses stream ``stream_base + i`` with ``gnn_dropout``; the
+    classifier uses ``stream_base + 64`` with ``pool_dropout``.
+    """
+    c = dict(DEFAULT_CFG, **cfg)
+    t = c["gnn_type"]
+    if "input_proj.weight" in p:                       # 05:168-171
+        x_in = F.linear(x, p["input_proj.weight"], p["input_proj.bias"])
+    else:
+        x_in = x
+    h, x0, hs = x_in, x_in, []
+    for i in range(c["gnn_layers"]):                   # 05:177-199
+        h_prev = h
+        if t == "mlp":
+            h = F.linear(h, p[f"gnn_layers.{i}.0.weight"], p[f"gnn_layers.{i}.0.bias"])
+        elif t == "gcn":
+            h = gcn_conv(h, edge_index, edge_weight, p[f"gnn_layers.{i}.lin.weight"], p[f"gnn_layers.{i}.bias"])
+        elif t == "gcnii":
+            h = gcn2_conv(h, x0, edge_index, edge_weight, p[f"gnn_layers.{i}.weight1"],
+                          c["gcnii_alpha"], c["gcnii_theta"], i + 1)
+        else:
+            raise ValueError(f"Unsupported gnn_type: {t}")
+        if c["use_layer_norm"]:
+            h = F.layer_norm(h, (h.shape[1],), p[f"layer_norms.{i}.weight"], p[f"layer_norms.{i}.bias"])
+        h = F.relu(h)
+        if drop is not None:
+            h = _mil.dropout(h, c["gnn_dropout"], drop["seed"], drop["stream_base"] + i)
+        if c["use_residual"] and h_prev.shape == h.shape:
+            h = h + h_prev
+        hs.append(h)
+    atts, pooled = [], []
+    for hd in range(c["att_heads"]):                   # 05:205-209
+        tt = torch.tanh(F.linear(h, p[f"attention_layers.{hd}.0.weight"], p[f"attention_layers.{hd}.0.bias"]))
+        a = torch.softmax(F.linear(tt, p[f"attention_layers.{hd}.2.weight"], p[f"attention_layers.{hd}.2.bias"]), dim=0)
+        atts.append(a)
+        pooled.append(torch.sum(a * h, dim=0))
+    z = torch.stack(pooled, dim=0).mean(dim=0)         # 05:212
+    att = torch.cat(atts, dim=1)                       # 05:213
+    u = F.relu(F.linear(z, p["classifier.0.weight"], p["classifier.0.bias"]))   # light head, 05:133-139
+    if drop is not None:
+        u = _mil.dropout(u, c["pool_dropout"], drop["seed"], drop["stream_base"] + 64)
+    logits = F.linear(u, p["classifier.3.weight"], p["classifier.3.bias"])
+    return {"probs": torch.softmax(logits, dim=0), "att": att, "hs": hs, "z": z, "logits": logits}
+
+
+def graph_loss(probs, y):
+    """`05_train_gnns.py:344`: CE(log(probs + 1e-9)[None], y).  Class weights of
+    `05:328-331` cancel for a single sample and are omitted."""
+    return F.cross_entropy(torch.log(probs + 1e-9).unsqueeze(0), torch.as_tensor(y).view(1).long())
+
+
+def graphmil_loss_and_grads(p, cfg, x, edge_index, y, edge_weight=None):
+    q = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    xx = x.detach().clone().requires_grad_(True)
+    out = graphmil_forward(q, cfg, xx, edge_index, edge_weight)
+    loss = graph_loss(out["probs"], y)
+    loss.backward()
+    g = {k: (v.grad.detach() if v.grad is not None else torch.zeros_like(v)) for k, v in q.items()}
+    g["x"] = xx.grad.detach()
+    out = {k: ([t.detach() for t in v] if isinstance(v, list) else v.detach()) for k, v in out.items()}
+    return loss.detach(), out, g

@@ -1,0 +1,115 @@
+"""ResNet-18 patch encoder on torch-CPU (oracle / test infrastructure).
+
+PARITY UNPINNED against the reference: the reference's patch encoder is an
+un-vendored ConvMAE (`save_latent.py:17-18,42-60`, `.gitignore:6`) with no
+weights in the tree; `BASELINE.json` configs[1] names ResNet-18 instead.  This
+file is the build's own definition of that encoder (He et al. 2015 basic-block
+ResNet-18, torchvision parameter names, no fc: global-average-pooled 512-d
+features), and it is what the HIP implicit-GEMM convolutions are checked
+against (SURVEY.md §8d layer table).
+
+``emulate_bf16=True`` rounds at exactly the points where the HIP path stores
+bf16 (conv inputs/weights/outputs, BN+ReLU outputs, activation gradients), with
+fp32 accumulation in between, so that the comparison isolates summation order.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+LAYERS = ((64, 1), (128, 2), (256, 2), (512, 2))  # (planes, stride of first block)
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def resnet18_shapes(in_ch=3):
+    s = OrderedDict()
+
+    def bn(prefix, c):
+        s[f"{prefix}.weight"] = (c,)
+        s[f"{prefix}.bias"] = (c,)
+
+    s["conv1.weight"] = (64, in_ch, 7, 7)
+    bn("bn1", 64)
+    inp = 64
+    for li, (planes, stride) in enumerate(LAYERS, start=1):
+        for b in range(2):
+            pre = f"layer{li}.{b}"
+            st = stride if b == 0 else 1
+            s[f"{pre}.conv1.weight"] = (planes, inp, 3, 3)
+            bn(f"{pre}.bn1", planes)
+            s[f"{pre}.conv2.weight"] = (planes, planes, 3, 3)
+            bn(f"{pre}.bn2", planes)
+            if st != 1 or inp != planes:
+                s[f"{pre}.downsample.0.weight"] = (planes, inp, 1, 1)
+                bn(f"{pre}.downsample.1", planes)
+            inp = planes
+    return s
+
+
+class _RoundBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+def _r(x, on):
+    return _RoundBF16.apply(x) if on else x
+
+
+def _bn_train(x, w, b, stats, name):
+    # batch statistics over (N,H,W), biased variance for normalisation
+    mean = x.mean(dim=(0, 2, 3))
+    var = x.var(dim=(0, 2, 3), unbiased=False)
+    if stats is not None:
+        stats[name] = (mean.detach(), var.detach())
+    inv = torch.rsqrt(var + BN_EPS)
+    return (x - mean[None, :, None, None]) * (inv * w)[None, :, None, None] + b[None, :, None, None]
+
+
+def resnet18_features(p, x, emulate_bf16=False, stats=None, taps=None):
+    """x[N,3,H,W] fp32 -> features[N,512] fp32 (train-mode BatchNorm)."""
+    e = emulate_bf16
+
+    def conv(t, name, stride, pad):
+        w = p[name]
+        if e:
+            w = _RoundBF16.apply(w)
+        return _r(F.conv2d(t, w, None, stride, pad), e)
+
+    def cbr(t, cname, bname, stride, pad, relu=True, residual=None):
+        c = conv(t, cname, stride, pad)
+        y = _bn_train(c, p[f"{bname}.weight"], p[f"{bname}.bias"], stats, bname)
+        if residual is not None:
+            y = y + residual
+        if relu:
+            y = F.relu(y)
+        return _r(y, e)
+
+    t = _r(x, e)
+    t = cbr(t, "conv1.weight", "bn1", 2, 3)
+    if taps is not None:
+        taps["stem"] = t
+    t = F.max_pool2d(t, 3, 2, 1)
+    if taps is not None:
+        taps["pool"] = t
+    inp = 64
+    for li, (planes, stride) in enumerate(LAYERS, start=1):
+        for b in range(2):
+            pre = f"layer{li}.{b}"
+            st = stride if b == 0 else 1
+            idt = t
+            if f"{pre}.downsample.0.weight" in p:
+                idt = cbr(t, f"{pre}.downsample.0.weight", f"{pre}.downsample.1", st, 0, relu=False)
+            u = cbr(t, f"{pre}.conv1.weight", f"{pre}.bn1", st, 1)
+            t = cbr(u, f"{pre}.conv2.weight", f"{pre}.bn2", 1, 1, relu=True, residual=idt)
+            inp = planes
+            if taps is not None:
+                taps[pre] = t
+    return t.mean(dim=(2, 3))
