@@ -1,0 +1,401 @@
+// Attention pooling over variable-length bags / graphs (gfx950).
+//
+// Replaces, for a whole batch of bags in ONE launch (the reference runs one bag
+// per Python call):
+//   utils_g_mil.py:72-97   AttentionMIL_teacher: scores -> softmax over the bag ->
+//                          class-space pooling of patch logits, patch/bag softmax
+//   utils_g_mil.py:32-33   AttentionMIL: feature-space pooling z = sum a*h
+//   05_train_gnns.py:205-213  GraphMIL multi-head pool, mean over heads
+//
+// HBM-bound: every h row and t row is read exactly once (forward) through
+// coalesced wave-wide loads; the softmax over the ragged bag is an online
+// (running max / running sum) reduction held in registers per wave and merged
+// across the 4 waves of the workgroup through LDS, so no second pass over h.
+// One 256-thread workgroup per bag; waves stride the bag's instances.
+#include "common.h"
+
+namespace {
+
+constexpr int NWAVE = 4;
+constexpr int MAX_HEADS = 4;   // heads per launch (host loops over groups of 4)
+constexpr int MAX_C = 16;
+
+struct PoolArgs {
+  const float* h; const float* t; const float* w3; const float* b3; const float* W4; const float* b4;
+  const int64_t* offsets;
+  int B, H, A, heads, C, max_bag;
+  int head0, heads_total;       // this launch handles heads [head0, head0+heads)
+  float* att; float* z; float* patch_logits; float* patch_probs; float* bag_logits; float* bag_probs;
+  int z_accumulate;
+};
+
+// dynamic LDS carve (floats):
+//   w3s[heads*A] | W4s[C*H] | sc[max_bag*heads] | wm[NWAVE*heads] | wl[NWAVE*heads] |
+//   wP[NWAVE*MAX_C] | wz[NWAVE*heads*H]
+template <int JH>
+__global__ __launch_bounds__(256) void attn_pool_fwd_kernel(PoolArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = a.H, A = a.A, NH = a.heads, C = a.C;
+  float* w3s = smem;
+  float* W4s = w3s + NH * A;
+  float* sc = W4s + (a.W4 ? C * H : 0);
+  float* wm = sc + a.max_bag * NH;
+  float* wl = wm + NWAVE * NH;
+  float* wP = wl + NWAVE * NH;
+  float* wz = wP + NWAVE * MAX_C;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  const int64_t lo = a.offsets[b], hi = a.offsets[b + 1];
+  const int nb = (int)(hi - lo);
+
+  for (int i = tid; i < NH * A; i += 256) w3s[i] = a.w3[(size_t)a.head0 * A + i];
+  if (a.W4)
+    for (int i = tid; i < C * H; i += 256) W4s[i] = a.W4[i];
+  __syncthreads();
+
+  float m[MAX_HEADS], l[MAX_HEADS], zacc[MAX_HEADS][JH], accP[MAX_C];
+#pragma unroll
+  for (int k = 0; k < MAX_HEADS; ++k) {
+    m[k] = -INFINITY; l[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < JH; ++j) zacc[k][j] = 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < MAX_C; ++c) accP[c] = 0.f;
+
+  const int At = a.heads_total * A;
+  for (int n = wave; n < nb; n += NWAVE) {
+    const float* hrow = a.h + (size_t)(lo + n) * H;
+    const float* trow = a.t + (size_t)(lo + n) * At + (size_t)a.head0 * A;
+    float hreg[JH];
+#pragma unroll
+    for (int j = 0; j < JH; ++j) {
+      const int col = lane + 64 * j;
+      hreg[j] = col < H ? hrow[col] : 0.f;
+    }
+    // class-space branch: P[n,c] = W4[c,:] . h[n,:] + b4[c]
+    float Pn[MAX_C];
+    if (a.W4) {
+#pragma unroll
+      for (int c = 0; c < MAX_C; ++c) {
+        if (c < C) {
+          float p = 0.f;
+#pragma unroll
+          for (int j = 0; j < JH; ++j) {
+            const int col = lane + 64 * j;
+            if (col < H) p += hreg[j] * W4s[c * H + col];
+          }
+          Pn[c] = wave_sum(p) + a.b4[c];
+        } else Pn[c] = 0.f;
+      }
+      if (a.patch_logits && lane < C) {
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAX_C; ++c) if (lane == c) v = Pn[c];
+        a.patch_logits[(size_t)(lo + n) * C + lane] = v;
+      }
+      if (a.patch_probs) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < MAX_C; ++c) if (c < C) mx = fmaxf(mx, Pn[c]);
+        float se = 0.f, mine = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAX_C; ++c) if (c < C) { const float e = expf(Pn[c] - mx); se += e; if (lane == c) mine = e; }
+        if (lane < C) a.patch_probs[(size_t)(lo + n) * C + lane] = mine / se;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < MAX_HEADS; ++k) {
+      if (k < NH) {
+        float p = 0.f;
+        for (int j = lane; j < A; j += 64) p += trow[k * A + j] * w3s[k * A + j];
+        const float s = wave_sum(p) + a.b3[a.head0 + k];
+        if (lane == 0) sc[n * NH + k] = s;
+        const float mn = fmaxf(m[k], s);
+        const float f = expf(m[k] - mn);   // exp(-inf) = 0 on the first instance
+        const float e = expf(s - mn);
+        l[k] = l[k] * f + e;
+        m[k] = mn;
+#pragma unroll
+        for (int j = 0; j < JH; ++j) zacc[k][j] = zacc[k][j] * f + e * hreg[j];
+        if (k == 0 && a.W4) {
+#pragma unroll
+          for (int c = 0; c < MAX_C; ++c) accP[c] = accP[c] * f + e * Pn[c];
+        }
+      }
+    }
+  }
+
+  // ---- merge the 4 waves
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < MAX_HEADS; ++k) if (k < NH) { wm[wave * NH + k] = m[k]; wl[wave * NH + k] = l[k]; }
+#pragma unroll
+    for (int c = 0; c < MAX_C; ++c) wP[wave * MAX_C + c] = accP[c];
+  }
+  if (a.z) {
+#pragma unroll
+    for (int k = 0; k < MAX_HEADS; ++k) if (k < NH) {
+#pragma unroll
+      for (int j = 0; j < JH; ++j) {
+        const int col = lane + 64 * j;
+        if (col < H) wz[(wave * NH + k) * H + col] = zacc[k][j];
+      }
+    }
+  }
+  __syncthreads();
+  float M[MAX_HEADS], L[MAX_HEADS], fw[MAX_HEADS][NWAVE];
+#pragma unroll
+  for (int k = 0; k < MAX_HEADS; ++k) {
+    M[k] = -INFINITY; L[k] = 0.f;
+    if (k < NH) {
+#pragma unroll
+      for (int w = 0; w < NWAVE; ++w) M[k] = fmaxf(M[k], wm[w * NH + k]);
+#pragma unroll
+      for (int w = 0; w < NWAVE; ++w) {
+        const float mw = wm[w * NH + k];
+        fw[k][w] = (mw == -INFINITY) ? 0.f : expf(mw - M[k]);
+        L[k] += wl[w * NH + k] * fw[k][w];
+      }
+    }
+  }
+  // attention weights
+  for (int i = tid; i < nb * NH; i += 256) {
+    const int n = i / NH, k = i - n * NH;
+    float Mk = 0.f, Lk = 1.f;
+#pragma unroll
+    for (int kk = 0; kk < MAX_HEADS; ++kk) if (kk == k) { Mk = M[kk]; Lk = L[kk]; }
+    a.att[(size_t)(lo + n) * a.heads_total + a.head0 + k] = expf(sc[i] - Mk) / Lk;
+  }
+  // pooled features: mean over ALL heads of sum_n a*h
+  if (a.z) {
+    const float inv_heads = 1.f / (float)a.heads_total;
+    for (int col = tid; col < H; col += 256) {
+      float zs = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAX_HEADS; ++k) if (k < NH && nb > 0) {
+        float zk = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) zk += wz[(w * NH + k) * H + col] * fw[k][w];
+        zs += zk / L[k];
+      }
+      zs *= inv_heads;
+      float* zp = a.z + (size_t)b * H + col;
+      *zp = a.z_accumulate ? *zp + zs : zs;
+    }
+  }
+  if (a.W4 && a.bag_logits && tid == 0) {
+    float bl[MAX_C], mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < MAX_C; ++c) {
+      bl[c] = 0.f;
+      if (c < C) {
+        if (nb > 0) {
+#pragma unroll
+          for (int w = 0; w < NWAVE; ++w) bl[c] += wP[w * MAX_C + c] * fw[0][w];
+          bl[c] /= L[0];
+        }
+        a.bag_logits[(size_t)b * C + c] = bl[c];
+        mx = fmaxf(mx, bl[c]);
+      }
+    }
+    if (a.bag_probs) {
+      float se = 0.f;
+#pragma unroll
+      for (int c = 0; c < MAX_C; ++c) if (c < C) { bl[c] = expf(bl[c] - mx); se += bl[c]; }
+#pragma unroll
+      for (int c = 0; c < MAX_C; ++c) if (c < C) a.bag_probs[(size_t)b * C + c] = bl[c] / se;
+    }
+  }
+}
+
+struct PoolBwdArgs {
+  const float* h; const float* t; const float* att; const float* P; const float* w3; const float* W4;
+  const int64_t* offsets;
+  int B, H, A, heads, C, max_bag;
+  const float* d_bag_logits; const float* d_z;
+  float* d_h; int accumulate_dh; float* d_u; float* d_s; float* d_P;
+};
+
+// LDS (floats): w3s[heads*A] | W4s[C*H] | dzs[H] | da[max_bag*heads] | red[NWAVE*heads]
+__global__ __launch_bounds__(256) void attn_pool_bwd_kernel(PoolBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = a.H, A = a.A, NH = a.heads, C = a.C;
+  float* w3s = smem;
+  float* W4s = w3s + NH * A;
+  float* dzs = W4s + (a.W4 ? C * H : 0);
+  float* da = dzs + H;
+  float* red = da + a.max_bag * NH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  const int64_t lo = a.offsets[b], hi = a.offsets[b + 1];
+  const int nb = (int)(hi - lo);
+  const float inv_heads = 1.f / (float)NH;
+
+  for (int i = tid; i < NH * A; i += 256) w3s[i] = a.w3[i];
+  if (a.W4)
+    for (int i = tid; i < C * H; i += 256) W4s[i] = a.W4[i];
+  for (int i = tid; i < H; i += 256) dzs[i] = a.d_z ? a.d_z[(size_t)b * H + i] : 0.f;
+  float dL[MAX_C];
+#pragma unroll
+  for (int c = 0; c < MAX_C; ++c) dL[c] = (a.d_bag_logits && c < C) ? a.d_bag_logits[(size_t)b * C + c] : 0.f;
+  __syncthreads();
+
+  // pass 1: da[n,k] = dL . P[n] (head 0 of the teacher form) + (1/heads) dz . h[n];  dot_k = sum_n a da
+  float dot[MAX_HEADS];
+#pragma unroll
+  for (int k = 0; k < MAX_HEADS; ++k) dot[k] = 0.f;
+  for (int n = wave; n < nb; n += NWAVE) {
+    float base = 0.f;
+    if (a.d_z) {
+      const float* hrow = a.h + (size_t)(lo + n) * H;
+      float p = 0.f;
+      for (int j = lane; j < H; j += 64) p += hrow[j] * dzs[j];
+      base = wave_sum(p) * inv_heads;
+    }
+    float cls = 0.f;
+    if (a.W4 && a.d_bag_logits) {
+      float p = 0.f;
+#pragma unroll
+      for (int c = 0; c < MAX_C; ++c) if (c < C && lane == c) p = dL[c] * a.P[(size_t)(lo + n) * C + c];
+      cls = wave_sum(p);
+    }
+#pragma unroll
+    for (int k = 0; k < MAX_HEADS; ++k) if (k < NH) {
+      const float d = base + (k == 0 ? cls : 0.f);
+      if (lane == 0) da[n * NH + k] = d;
+      dot[k] += a.att[(size_t)(lo + n) * NH + k] * d;
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < MAX_HEADS; ++k) if (k < NH) red[wave * NH + k] = dot[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < MAX_HEADS; ++k) if (k < NH) {
+    dot[k] = (red[0 * NH + k] + red[1 * NH + k]) + (red[2 * NH + k] + red[3 * NH + k]);
+  }
+
+  // pass 2
+  const int At = NH * A;
+  for (int n = wave; n < nb; n += NWAVE) {
+    float an[MAX_HEADS], ds[MAX_HEADS];
+#pragma unroll
+    for (int k = 0; k < MAX_HEADS; ++k) {
+      an[k] = 0.f; ds[k] = 0.f;
+      if (k < NH) {
+        an[k] = a.att[(size_t)(lo + n) * NH + k];
+        ds[k] = an[k] * (da[n * NH + k] - dot[k]);
+        if (a.d_s && lane == 0) a.d_s[(size_t)(lo + n) * NH + k] = ds[k];
+      }
+    }
+    if (a.d_u) {
+      const float* trow = a.t + (size_t)(lo + n) * At;
+      float* urow = a.d_u + (size_t)(lo + n) * At;
+#pragma unroll
+      for (int k = 0; k < MAX_HEADS; ++k) if (k < NH) {
+        for (int j = lane; j < A; j += 64) {
+          const float tv = trow[k * A + j];
+          urow[k * A + j] = ds[k] * w3s[k * A + j] * (1.f - tv * tv);
+        }
+      }
+    }
+    if (a.W4 && a.d_P && lane < C) {
+      float v = 0.f;
+#pragma unroll
+      for (int c = 0; c < MAX_C; ++c) if (lane == c) v = an[0] * dL[c];
+      a.d_P[(size_t)(lo + n) * C + lane] = v;
+    }
+    if (a.d_h) {
+      float asum = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAX_HEADS; ++k) if (k < NH) asum += an[k];
+      asum *= inv_heads;
+      float* drow = a.d_h + (size_t)(lo + n) * H;
+      for (int j = lane; j < H; j += 64) {
+        float v = asum * dzs[j];
+        if (a.W4 && a.d_bag_logits) {
+#pragma unroll
+          for (int c = 0; c < MAX_C; ++c) if (c < C) v += W4s[c * H + j] * (an[0] * dL[c]);
+        }
+        drow[j] = a.accumulate_dh ? drow[j] + v : v;
+      }
+    }
+  }
+}
+
+template <typename K>
+int ensure_lds(K kernel, size_t bytes) {
+  if (bytes > 160 * 1024) return ISIC_ERR_UNSUPPORTED;
+  if (bytes > 48 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) != hipSuccess)
+      return ISIC_ERR_LAUNCH;
+  }
+  return ISIC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int isic_attn_pool_fwd(const float* h, const float* t, const float* w3, const float* b3, const float* W4,
+                       const float* b4, const int64_t* offsets, int B, int H, int A, int heads, int C, int max_bag,
+                       float* att, float* z, float* patch_logits, float* patch_probs, float* bag_logits,
+                       float* bag_probs, void* stream) {
+  ISIC_CHECK_ARG(B >= 0 && H > 0 && A > 0 && heads > 0 && max_bag >= 0);
+  if (B == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(h && t && w3 && b3 && offsets && att);
+  if (W4) { ISIC_CHECK_ARG(heads == 1 && C > 0 && b4); if (C > MAX_C) return ISIC_ERR_UNSUPPORTED; }
+  if (H > 1024) return ISIC_ERR_UNSUPPORTED;
+  for (int head0 = 0; head0 < heads; head0 += MAX_HEADS) {
+    const int nh = heads - head0 < MAX_HEADS ? heads - head0 : MAX_HEADS;
+    PoolArgs a;
+    a.h = h; a.t = t; a.w3 = w3; a.b3 = b3; a.W4 = W4; a.b4 = b4; a.offsets = offsets;
+    a.B = B; a.H = H; a.A = A; a.heads = nh; a.C = W4 ? C : 0; a.max_bag = max_bag;
+    a.head0 = head0; a.heads_total = heads;
+    a.att = att; a.z = z; a.patch_logits = patch_logits; a.patch_probs = patch_probs;
+    a.bag_logits = bag_logits; a.bag_probs = bag_probs; a.z_accumulate = head0 > 0;
+    const size_t lds = sizeof(float) * ((size_t)nh * A + (W4 ? (size_t)C * H : 0) + (size_t)max_bag * nh +
+                                        2 * NWAVE * nh + NWAVE * MAX_C + (size_t)NWAVE * nh * H);
+    int rc;
+#define LAUNCH_POOL(JH)                                                                             \
+  rc = ensure_lds(attn_pool_fwd_kernel<JH>, lds);                                                   \
+  if (rc != ISIC_OK) return rc;                                                                     \
+  hipLaunchKernelGGL(attn_pool_fwd_kernel<JH>, dim3(B), dim3(256), lds, as_stream(stream), a)
+    if (H <= 128) { LAUNCH_POOL(2); }
+    else if (H <= 256) { LAUNCH_POOL(4); }
+    else if (H <= 512) { LAUNCH_POOL(8); }
+    else { LAUNCH_POOL(16); }
+#undef LAUNCH_POOL
+    rc = isic_launch_status();
+    if (rc != ISIC_OK) return rc;
+  }
+  return ISIC_OK;
+}
+
+int isic_attn_pool_bwd(const float* h, const float* t, const float* att, const float* patch_logits,
+                       const float* w3, const float* W4, const int64_t* offsets, int B, int H, int A, int heads,
+                       int C, int max_bag, const float* d_bag_logits, const float* d_z, float* d_h,
+                       int accumulate_dh, float* d_u, float* d_s, float* d_P, void* stream) {
+  ISIC_CHECK_ARG(B >= 0 && H > 0 && A > 0 && heads > 0 && max_bag >= 0);
+  if (B == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(h && t && att && w3 && offsets);
+  if (heads > MAX_HEADS) return ISIC_ERR_UNSUPPORTED;
+  if (W4) { ISIC_CHECK_ARG(heads == 1 && C > 0 && patch_logits); if (C > MAX_C) return ISIC_ERR_UNSUPPORTED; }
+  PoolBwdArgs a;
+  a.h = h; a.t = t; a.att = att; a.P = patch_logits; a.w3 = w3; a.W4 = W4; a.offsets = offsets;
+  a.B = B; a.H = H; a.A = A; a.heads = heads; a.C = W4 ? C : 0; a.max_bag = max_bag;
+  a.d_bag_logits = d_bag_logits; a.d_z = d_z; a.d_h = d_h; a.accumulate_dh = accumulate_dh;
+  a.d_u = d_u; a.d_s = d_s; a.d_P = d_P;
+  const size_t lds = sizeof(float) * ((size_t)heads * A + (W4 ? (size_t)C * H : 0) + H + (size_t)max_bag * heads +
+                                      NWAVE * heads);
+  int rc = ensure_lds(attn_pool_bwd_kernel, lds);
+  if (rc != ISIC_OK) return rc;
+  hipLaunchKernelGGL(attn_pool_bwd_kernel, dim3(B), dim3(256), lds, as_stream(stream), a);
+  return isic_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+// Shared device/host helpers for libisic_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/isic_hip.h"
+
+#define ISIC_WAVE 64
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define ISIC_CHECK_ARG(cond) \
+  do {                       \
+    if (!(cond)) return ISIC_ERR_BAD_ARG; \
+  } while (0)
+
+static inline int isic_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ISIC_OK : ISIC_ERR_LAUNCH;
+}
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+__host__ __device__ static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- bf16 <-> f32
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+  return __uint_as_float(((unsigned int)b) << 16);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+  // plain cast: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN preserved)
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, h);
+}
+
+// ---------------------------------------------------------------- wave reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------- Philox4x32-10
+// Bit-for-bit the generator restated in oracle/philox.py.
+struct Philox4 {
+  unsigned int x, y, z, w;
+};
+__host__ __device__ static inline Philox4 philox4x32_10(unsigned int c0, unsigned int c1, unsigned int c2,
+                                                        unsigned int c3, unsigned int k0, unsigned int k1) {
+  const unsigned int M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    unsigned long long p0 = (unsigned long long)M0 * c0;
+    unsigned long long p1 = (unsigned long long)M1 * c2;
+    unsigned int hi0 = (unsigned int)(p0 >> 32), lo0 = (unsigned int)p0;
+    unsigned int hi1 = (unsigned int)(p1 >> 32), lo1 = (unsigned int)p1;
+    unsigned int n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  Philox4 o = {c0, c1, c2, c3};
+  return o;
+}
+// word (i & 3) of block (i >> 2) of the (seed, stream) sequence
+__host__ __device__ static inline unsigned int philox_word(unsigned long long i, unsigned long long seed,
+                                                           unsigned long long stream) {
+  unsigned long long blk = i >> 2;
+  Philox4 r = philox4x32_10((unsigned int)blk, (unsigned int)(blk >> 32), (unsigned int)stream,
+                            (unsigned int)(stream >> 32), (unsigned int)seed, (unsigned int)(seed >> 32));
+  switch (i & 3) {
+    case 0: return r.x;
+    case 1: return r.y;
+    case 2: return r.z;
+    default: return r.w;
+  }
+}
+// keep-mask for 4 consecutive elements starting at a multiple of 4
+__device__ __forceinline__ Philox4 philox_block(unsigned long long blk, unsigned long long seed,
+                                                unsigned long long stream) {
+  return philox4x32_10((unsigned int)blk, (unsigned int)(blk >> 32), (unsigned int)stream,
+                       (unsigned int)(stream >> 32), (unsigned int)seed, (unsigned int)(seed >> 32));
+}
+__host__ __device__ static inline unsigned int dropout_threshold(float p) {
+  double t = floor((double)p * 4294967296.0);
+  return t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned int)t;
+}

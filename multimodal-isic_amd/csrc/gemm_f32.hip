@@ -1,0 +1,249 @@
+// Exact-fp32 dense GEMM on v_mfma_f32_16x16x4_f32 (gfx950).
+//   C[M,N] = act(op(A)[M,K] * op(B)[K,N] + bias[N]) + beta * C
+// Replaces the nn.Linear layers (and their autograd backward) of the reference's
+// MIL head (utils_g_mil.py:49-63), GraphMIL (05_train_gnns.py:66,112,126-139)
+// and radiomic MLP / fusion head (model.py:74-83,138-143).
+//
+// Tiling: 256 threads = 4 waves (2x2), block tile 64x64, BK = 16; each wave owns
+// a 32x32 sub-tile = 2x2 MFMA tiles.  Both operands are staged in LDS as
+// [row][k] with k contiguous, so one ds_read_b128 feeds four MFMA k-steps: within
+// a 16-deep chunk lane-group g (= lane>>4) supplies k = 4g + j at step j for A
+// and for B alike (any permutation of k is a valid summation order as long as
+// both operands use it).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 16, LDT = BK + 4;  // 80-byte rows: 16-B aligned, conflict-light
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  int M, N, K, lda, ldb, ldc;
+  int transA, transB, act, vecA, vecB;
+  float beta;
+};
+
+// Load 4 consecutive elements (along the contiguous dim) of a row-major matrix
+// with R rows x Cc cols, zero-filled outside.
+__device__ __forceinline__ float4 load4(const float* __restrict__ p, int ld, int r, int c, int R, int Cc, int vec) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r >= R) return v;
+  const float* q = p + (size_t)r * ld + c;
+  if (vec && c + 3 < Cc) return *reinterpret_cast<const float4*>(q);
+  if (c < Cc) v.x = q[0];
+  if (c + 1 < Cc) v.y = q[1];
+  if (c + 2 < Cc) v.z = q[2];
+  if (c + 3 < Cc) v.w = q[3];
+  return v;
+}
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[BM * LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // staging coordinates
+  // k-contiguous source: thread -> (row = tid>>2, kq = (tid&3)*4)
+  // row-contiguous source: thread -> (k = tid>>4, rq = (tid&15)*4)
+  const int rowK = tid >> 2, kqK = (tid & 3) * 4;
+  const int kR = tid >> 4, rqR = (tid & 15) * 4;
+
+  const int nk = (a.K + BK - 1) / BK;
+  float4 ra, rb;
+  auto gload = [&](int kt) {
+    const int k0 = kt * BK;
+    if (!a.transA) ra = load4(a.A, a.lda, m0 + rowK, k0 + kqK, a.M, a.K, a.vecA);
+    else ra = load4(a.A, a.lda, k0 + kR, m0 + rqR, a.K, a.M, a.vecA);
+    if (a.transB) rb = load4(a.B, a.ldb, n0 + rowK, k0 + kqK, a.N, a.K, a.vecB);
+    else rb = load4(a.B, a.ldb, k0 + kR, n0 + rqR, a.K, a.N, a.vecB);
+  };
+  auto lstore = [&]() {
+    if (!a.transA) *reinterpret_cast<float4*>(&As[rowK * LDT + kqK]) = ra;
+    else {
+      As[(rqR + 0) * LDT + kR] = ra.x; As[(rqR + 1) * LDT + kR] = ra.y;
+      As[(rqR + 2) * LDT + kR] = ra.z; As[(rqR + 3) * LDT + kR] = ra.w;
+    }
+    if (a.transB) *reinterpret_cast<float4*>(&Bs[rowK * LDT + kqK]) = rb;
+    else {
+      Bs[(rqR + 0) * LDT + kR] = rb.x; Bs[(rqR + 1) * LDT + kR] = rb.y;
+      Bs[(rqR + 2) * LDT + kR] = rb.z; Bs[(rqR + 3) * LDT + kR] = rb.w;
+    }
+  };
+
+  gload(0);
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();  // previous tile fully consumed
+    lstore();
+    __syncthreads();
+    if (kt + 1 < nk) gload(kt + 1);
+    float4 af[2], bf[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      af[i] = *reinterpret_cast<const float4*>(&As[(wm * 32 + i * 16 + fr) * LDT + 4 * fg]);
+      bf[i] = *reinterpret_cast<const float4*>(&Bs[(wn * 32 + i * 16 + fr) * LDT + 4 * fg]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+      }
+  }
+
+  // epilogue: C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 32 + j * 16 + fr;
+      if (col >= a.N) continue;
+      const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 32 + i * 16 + fg * 4 + r;
+        if (row >= a.M) continue;
+        float v = acc[i][j][r] + bv;
+        if (a.act == ISIC_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (a.act == ISIC_ACT_TANH) v = tanhf(v);
+        float* cp = a.C + (size_t)row * a.ldc + col;
+        if (a.beta != 0.f) v += a.beta * (*cp);
+        *cp = v;
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, int ldx,
+                                                      float* __restrict__ out, float beta) {
+  // one block per 64 columns; 4 waves stride the rows; deterministic tree over waves
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (col < N)
+    for (int r = wave; r < M; r += 4) s += X[(size_t)r * ldx + col];
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && col < N) {
+    float t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    out[col] = beta != 0.f ? beta * out[col] + t : t;
+  }
+}
+
+__global__ void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ t, float* __restrict__ dx,
+                                int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const float tv = t[i];
+    dx[i] = dy[i] * (1.f - tv * tv);
+  }
+}
+
+__global__ void relu_dropout_fwd_kernel(float* __restrict__ x, int64_t n, unsigned int thr, float scale,
+                                        unsigned long long seed, unsigned long long stream_id) {
+  // each thread handles one Philox block = 4 consecutive elements
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nb = (n + 3) >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+  for (; b < nb; b += stride) {
+    Philox4 r = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (thr) r = philox_block((unsigned long long)b, seed, stream_id);
+    const unsigned int w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t i = b * 4 + j;
+      if (i < n) {
+        float v = fmaxf(x[i], 0.f);
+        if (thr) v = (w[j] >= thr) ? v * scale : 0.f;
+        x[i] = v;
+      }
+    }
+  }
+}
+
+__global__ void relu_dropout_bwd_kernel(const float* __restrict__ y, float* __restrict__ dy, int64_t n,
+                                        float scale) {
+  // y = dropout(relu(x)): y > 0 <=> x > 0 and kept, so the mask is recovered from y itself
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dy[i] = y[i] > 0.f ? dy[i] * scale : 0.f;
+}
+
+inline int grid_for(int64_t n, int block) {
+  int64_t g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int isic_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                  float* C, int ldc, const float* bias, int act, float beta, void* stream) {
+  ISIC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0);
+  if (M == 0 || N == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(A && B && C);
+  ISIC_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N);
+  ISIC_CHECK_ARG(act >= ISIC_ACT_NONE && act <= ISIC_ACT_TANH);
+  GemmArgs a;
+  a.A = A; a.B = B; a.C = C; a.bias = bias;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.transA = transA; a.transB = transB; a.act = act; a.beta = beta;
+  a.vecA = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  a.vecB = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  dim3 grid(ceil_div(M, BM), ceil_div(N, BN));
+  ISIC_CHECK_ARG(grid.y <= 65535u);
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, as_stream(stream), a);
+  return isic_launch_status();
+}
+
+int isic_colsum_f32(const float* X, int M, int N, int ldx, float* out, float beta, void* stream) {
+  ISIC_CHECK_ARG(M >= 0 && N >= 0 && ldx >= N);
+  if (N == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(X && out);
+  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64)), dim3(256), 0, as_stream(stream), X, M, N, ldx, out, beta);
+  return isic_launch_status();
+}
+
+int isic_tanh_bwd_f32(const float* dy, const float* t, float* dx, int64_t n, void* stream) {
+  ISIC_CHECK_ARG(n >= 0);
+  if (n == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(dy && t && dx);
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), dy, t, dx, n);
+  return isic_launch_status();
+}
+
+int isic_relu_dropout_fwd_f32(float* x, int64_t n, uint32_t drop_threshold, float drop_scale, uint64_t seed,
+                              uint64_t stream_id, void* stream) {
+  ISIC_CHECK_ARG(n >= 0);
+  if (n == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(x);
+  hipLaunchKernelGGL(relu_dropout_fwd_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, as_stream(stream), x, n,
+                     drop_threshold, drop_scale, (unsigned long long)seed, (unsigned long long)stream_id);
+  return isic_launch_status();
+}
+
+int isic_relu_dropout_bwd_f32(const float* y, float* dy, int64_t n, float drop_scale, void* stream) {
+  ISIC_CHECK_ARG(n >= 0);
+  if (n == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(y && dy);
+  hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), y, dy, n,
+                     drop_scale);
+  return isic_launch_status();
+}
+
+}  // extern "C"

