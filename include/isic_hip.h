@@ -136,6 +136,78 @@ int isic_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
                    float eps, float decay_factor, float l2, float bias_correction2_sqrt, float grad_scale,
                    uint16_t* p_bf16, void* stream);
 
+/* ------------------------------------------------------------------ patch encoder (bf16 MFMA, NHWC)
+ * The reference's encoder is an un-vendored ConvMAE run through torch
+ * (save_latent.py:42-60); BASELINE.json configs[1] names ResNet-18 (layer table:
+ * SURVEY.md 8d).  Activations are NHWC bf16, weights are [Cout][Kh][Kw][Cin]
+ * (= torch channels_last memory of an OIHW parameter), accumulation fp32.
+ *
+ * isic_conv2d_igemm_bf16: implicit-GEMM convolution, forward AND data gradient:
+ *   out[n,ho,wo,co] = sum_{kh,kw,ci} in[n, (ho*up+kh-pad)/down, (wo*up+kw-pad)/down, ci] * w[co,kh,kw,ci]
+ *   (taps whose source pixel is fractional or outside the image contribute zero)
+ *   forward: up = stride, down = 1, pad = padding, w = bf16 W[co][kh][kw][ci]
+ *   dgrad:   up = 1, down = stride, pad = k-1-padding, in = dY, w = W flipped+transposed [ci][kh][kw][co]
+ * Cin and Cout must be multiples of 64; down in {1,2,4}. */
+int isic_conv2d_igemm_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int Hin, int Win, int Cin,
+                           int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad, void* stream);
+/* dW[co][kh][kw][ci] (fp32, ACCUMULATED with atomics into the caller's zeroed or
+ * running gradient) = sum_{n,ho,wo} dY[n,ho,wo,co] * X[n,ho*stride+kh-pad,wo*stride+kw-pad,ci].
+ * N*Hout*Wout < 2^24 per call (the caller chunks larger batches). */
+int isic_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dw, int N, int Hin, int Win, int Cin,
+                           int Hout, int Wout, int Cout, int Kh, int Kw, int stride, int pad, void* stream);
+/* fp32 master weights [O][Kh][Kw][I] -> bf16 forward copy (same order) and bf16
+ * dgrad copy [I][Kh][Kw][O] with both taps flipped (either may be NULL). */
+int isic_conv_weight_prep_bf16(const float* w_krsc, uint16_t* w_fwd, uint16_t* w_dgrad, int O, int I, int Kh, int Kw,
+                               void* stream);
+/* Stem: 7x7/2 pad 3, 3->64, on NHWC input with C padded to 4.  w_stem is
+ * [64][7][8][4] bf16 (kw, ci zero padded) made by isic_conv_stem_pack_bf16 from the
+ * fp32 [64][7][7][3] parameter; the weight gradient accumulates (atomics) into
+ * fp32 [64][7][7][3]. */
+int isic_conv_stem_fwd_bf16(const uint16_t* in_nhwc4, const uint16_t* w_stem, uint16_t* out, int N, int Hin, int Win,
+                            int Hout, int Wout, void* stream);
+int isic_conv_stem_wgrad_bf16(const uint16_t* in_nhwc4, const uint16_t* dy, float* dw, int N, int Hin, int Win,
+                              int Hout, int Wout, void* stream);
+int isic_conv_stem_pack_bf16(const float* w_krsc, uint16_t* w_stem, void* stream);
+/* NCHW fp32/bf16 images (the reference's dataset layout, dataset.py:36-40) ->
+ * NHWC bf16 with C padded to 4. */
+int isic_nchw_to_nhwc4_bf16(const void* in, int in_is_bf16, uint16_t* out, int N, int C, int H, int W, void* stream);
+
+/* BatchNorm2d, training mode, NHWC bf16.  stats: per-channel sum / sum of squares
+ * in fp64 (zeroed by the caller); finalize: scale = gamma*rstd, shift = beta -
+ * mean*scale, running stats updated with `momentum` (unbiased variance). */
+int isic_bn_stats_bf16(const uint16_t* x, int64_t rows, int C, double* sum, double* sumsq, void* stream);
+int isic_bn_finalize(const double* sum, const double* sumsq, int64_t rows, int C, const float* gamma,
+                     const float* beta, float eps, float momentum, float* scale, float* shift, float* mean,
+                     float* rstd, float* running_mean, float* running_var, void* stream);
+/* eval mode: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale */
+int isic_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                        float eps, int C, float* scale, float* shift, void* stream);
+/* y = relu?(x*scale + shift + residual) */
+int isic_bn_apply_bf16(const uint16_t* x, const float* scale, const float* shift, const uint16_t* residual,
+                       uint16_t* y, int64_t rows, int C, int relu, void* stream);
+/* backward in two passes.  reduce: dz = dy * (y > 0 if relu); dbeta = sum dz,
+ * dgamma = sum dz*xhat (fp64, zeroed by the caller).  apply: dx = gamma*rstd *
+ * (dz - dbeta/rows - xhat*dgamma/rows); d_residual = dz (optional); the fp32
+ * parameter gradients get += dgamma/dbeta (optional). */
+int isic_bn_bwd_reduce_bf16(const uint16_t* dy, const uint16_t* x, const uint16_t* y, const float* mean,
+                            const float* rstd, int64_t rows, int C, int relu, double* dgamma, double* dbeta,
+                            void* stream);
+int isic_bn_bwd_apply_bf16(const uint16_t* dy, const uint16_t* x, const uint16_t* y, const float* mean,
+                           const float* rstd, const float* gamma, const double* dgamma, const double* dbeta,
+                           int64_t rows, int C, int relu, uint16_t* dx, uint16_t* d_residual, float* dgamma_f32,
+                           float* dbeta_f32, void* stream);
+/* MaxPool 3x3/2 pad 1 (first maximum wins, like torch); argmax[N,Ho,Wo,C] holds the
+ * winning tap kh*3+kw for the backward pass. */
+int isic_maxpool3x3s2_fwd_bf16(const uint16_t* x, uint16_t* y, uint8_t* argmax, int N, int H, int W, int C, int Ho,
+                               int Wo, void* stream);
+int isic_maxpool3x3s2_bwd_bf16(const uint8_t* argmax, const uint16_t* dy, uint16_t* dx, int N, int H, int W, int C,
+                               int Ho, int Wo, void* stream);
+/* Global average pool NHWC bf16 -> [N,C] fp32, and backward -> bf16. */
+int isic_avgpool_fwd_bf16(const uint16_t* x, float* y, int N, int HW, int C, void* stream);
+int isic_avgpool_bwd_bf16(const float* dy, uint16_t* dx, int N, int HW, int C, void* stream);
+/* a += b on bf16 tensors (gradient join of a residual block); n % 8 == 0. */
+int isic_add_bf16(uint16_t* a, const uint16_t* b, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,245 @@
+// ResNet stem convolution 7x7 / stride 2 / pad 3, 3 -> 64 channels, on bf16 MFMA (gfx950).
+//
+// Cin = 3 is too thin for the generic implicit GEMM (K-tiles of 64 channels), so the stem gets its
+// own direct kernels.  The input is NHWC with C padded to 4 (8 bytes per pixel); a block stages the
+// (21 x 40)-pixel input patch of an 8 x 16 output tile in LDS once and every MFMA A-fragment is a
+// single ds_read_b128 out of it: for output pixel (oy,ox) and kernel row kh the 8 taps kw = 0..7
+// (the 8th is a zero-weight pad) x 4 channels are 32 CONTIGUOUS bf16 of patch row 2*oy+kh starting
+// at column 2*ox, so K = 7 steps of 32.  Weights are packed [64][7][8][4] (kw, c zero padded).
+//
+// The weight gradient uses the same patch: K = pixels, the dY tile is staged [pixel][co] and both
+// operands are fetched with the transposing LDS read ds_read_b64_tr_b16 (for the input operand each
+// lane addresses its own pixel's 4 taps x 4 channels = 8 contiguous bytes).
+//
+// No counterpart in the reference (encoder un-vendored, save_latent.py:42-60); ResNet-18 layer
+// table: SURVEY.md 8d (conv1: 118 MMAC per 224x224 image).
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 16;             // output tile
+constexpr int PR = 2 * TH + 5, PC = 40;    // patch rows (21) / cols (38 used, 40 allocated)
+constexpr int PROW = PC * 8;               // bytes per patch row (4 bf16 per pixel)
+constexpr int WROW = 7 * 64 + 16;          // bytes per co row of the LDS weight image (padded: conflict-free)
+constexpr int CPAD = 72;                   // epilogue row stride (elements)
+constexpr int YROW = 128 + 32;             // bytes per pixel row of the staged dY tile
+
+struct StemArgs {
+  const unsigned short* in;   // [N,Hin,Win,4]
+  const unsigned short* w;    // [64][7][8][4]
+  unsigned short* out;        // [N,Hout,Wout,64]
+  const unsigned short* dy;   // wgrad: [N,Hout,Wout,64]
+  float* dw;                  // wgrad: [64][7][7][3] fp32
+  int N, Hin, Win, Hout, Wout, tiles_h, tiles_w, total_tiles;
+};
+
+__device__ __forceinline__ void load_patch(unsigned char* Ps, const StemArgs& a, int n, int oy0, int ox0, int tid) {
+  // patch pixel (pr, pc) = input pixel (2*oy0 - 3 + pr, 2*ox0 - 3 + pc); 8 bytes each
+  for (int idx = tid; idx < PR * PC; idx += 256) {
+    const int pr = idx / PC, pc = idx - pr * PC;
+    const int hi = 2 * oy0 - 3 + pr, wi = 2 * ox0 - 3 + pc;
+    u32x2 v = {0u, 0u};
+    if (hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win)
+      v = *reinterpret_cast<const u32x2*>(a.in + (((size_t)n * a.Hin + hi) * a.Win + wi) * 4);
+    *reinterpret_cast<u32x2*>(Ps + pr * PROW + pc * 8) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_stem_fwd_kernel(StemArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[64 * WROW + PR * PROW + TH * TW * CPAD * 2];
+  unsigned char* Ws = smem;
+  unsigned char* Ps = smem + 64 * WROW;
+  unsigned short* Cs = reinterpret_cast<unsigned short*>(smem + 64 * WROW + PR * PROW);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fi = lane & 15, fg = lane >> 4;
+
+  // weights -> LDS once per block: 64 rows x 448 bytes (28 chunks of 16 B)
+  for (int idx = tid; idx < 64 * 28; idx += 256) {
+    const int co = idx / 28, ch = idx - co * 28;
+    *reinterpret_cast<u32x4*>(Ws + co * WROW + ch * 16) = *reinterpret_cast<const u32x4*>(a.w + co * 224 + ch * 8);
+  }
+
+  for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+    const int n = tile / (a.tiles_h * a.tiles_w);
+    const int t2 = tile - n * (a.tiles_h * a.tiles_w);
+    const int oy0 = (t2 / a.tiles_w) * TH, ox0 = (t2 % a.tiles_w) * TW;
+    __syncthreads();  // previous tile's epilogue reads done / weights visible
+    load_patch(Ps, a, n, oy0, ox0, tid);
+    __syncthreads();
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh) {
+      bf16x8 af[2], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int oyl = wave * 2 + i;
+        af[i] = *reinterpret_cast<const bf16x8*>(Ps + (2 * oyl + kh) * PROW + (2 * fi + 2 * fg) * 8);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8*>(Ws + (j * 16 + fi) * WROW + kh * 64 + fg * 16);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    // epilogue through LDS: pixel index p = oyl*16 + oxl, row-major [p][co]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int p = (wave * 2 + i) * 16 + fg * 4 + r;
+          Cs[p * CPAD + j * 16 + fi] = f32_to_bf16_bits(acc[i][j][r]);
+        }
+    __syncthreads();
+    for (int idx = tid; idx < TH * TW * 8; idx += 256) {
+      const int p = idx >> 3, ch = idx & 7;
+      const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
+      if (oy < a.Hout && ox < a.Wout)
+        *reinterpret_cast<u32x4*>(a.out + (((size_t)n * a.Hout + oy) * a.Wout + ox) * 64 + ch * 8) =
+            *reinterpret_cast<const u32x4*>(Cs + p * CPAD + ch * 8);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(StemArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[PR * PROW + TH * TW * YROW];
+  unsigned char* Ps = smem;
+  unsigned char* Ys = smem + PR * PROW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fg = lane >> 4, fi = lane & 15, fq = fi >> 2, fp = fi & 3;
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+
+  // n-tiles: nt = kh*2 + half (14 of them); wave w owns nt = w, w+4, w+8, w+12
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+    const int n = tile / (a.tiles_h * a.tiles_w);
+    const int t2 = tile - n * (a.tiles_h * a.tiles_w);
+    const int oy0 = (t2 / a.tiles_w) * TH, ox0 = (t2 % a.tiles_w) * TW;
+    __syncthreads();
+    load_patch(Ps, a, n, oy0, ox0, tid);
+    for (int idx = tid; idx < TH * TW * 8; idx += 256) {
+      const int p = idx >> 3, ch = idx & 7;
+      const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (oy < a.Hout && ox < a.Wout)
+        v = *reinterpret_cast<const u32x4*>(a.dy + (((size_t)n * a.Hout + oy) * a.Wout + ox) * 64 + ch * 8);
+      *reinterpret_cast<u32x4*>(Ys + p * YROW + ch * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int k1 = ks * 32 + 8 * fg + fq, k2 = k1 + 4;   // the two pixel rows this lane addresses
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Ys + k1 * YROW + (i * 16 + 4 * fp) * 2));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Ys + k2 * YROW + (i * 16 + 4 * fp) * 2));
+        s16x8_t t; t.lo = lo; t.hi = hi;
+        af[i] = __builtin_bit_cast(bf16x8, t);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int nt = wave + 4 * j;
+        const int kh = nt >> 1, half = nt & 1;
+        // nt >= 14 would address past the taps: clamp the address (result discarded at the end)
+        const int khc = kh > 6 ? 6 : kh;
+        const unsigned char* p1 = Ps + (2 * (k1 >> 4) + khc) * PROW + (2 * (k1 & 15) + half * 4 + fp) * 8;
+        const unsigned char* p2 = Ps + (2 * (k2 >> 4) + khc) * PROW + (2 * (k2 & 15) + half * 4 + fp) * 8;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)p1);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)p2);
+        s16x8_t t; t.lo = lo; t.hi = hi;
+        bfr[j] = __builtin_bit_cast(bf16x8, t);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // dw[co][kh][kw][c], c < 3, kw < 7
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nt = wave + 4 * j;
+      if (nt >= 14) continue;
+      const int kh = nt >> 1, kw = (nt & 1) * 4 + (fi >> 2), c = fi & 3;
+      if (kw >= 7 || c >= 3) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = i * 16 + fg * 4 + r;
+        atomicAdd(a.dw + ((co * 7 + kh) * 7 + kw) * 3 + c, acc[i][j][r]);
+      }
+    }
+}
+
+// fp32 [64][7][7][3] (channels_last memory of the OIHW parameter) -> bf16 [64][7][8][4], zero padded
+__global__ void stem_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ ws) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 64 * 7 * 8 * 4) return;
+  const int c = idx & 3, kw = (idx >> 2) & 7, kh = (idx >> 5) % 7, co = idx / 224;
+  float v = 0.f;
+  if (c < 3 && kw < 7) v = w[((co * 7 + kh) * 7 + kw) * 3 + c];
+  ws[idx] = f32_to_bf16_bits(v);
+}
+
+int stem_args(StemArgs& a, int N, int Hin, int Win, int Hout, int Wout) {
+  if (Hout != (Hin + 6 - 7) / 2 + 1 || Wout != (Win + 6 - 7) / 2 + 1) return ISIC_ERR_BAD_ARG;
+  a.N = N; a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout;
+  a.tiles_h = ceil_div(Hout, TH); a.tiles_w = ceil_div(Wout, TW);
+  const int64_t tt = (int64_t)N * a.tiles_h * a.tiles_w;
+  if (tt > 0x7FFFFFFFLL) return ISIC_ERR_UNSUPPORTED;
+  a.total_tiles = (int)tt;
+  return ISIC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int isic_conv_stem_fwd_bf16(const uint16_t* in_nhwc4, const uint16_t* w_stem, uint16_t* out, int N, int Hin, int Win,
+                            int Hout, int Wout, void* stream) {
+  ISIC_CHECK_ARG(in_nhwc4 && w_stem && out && N > 0 && Hin > 0 && Win > 0);
+  StemArgs a;
+  a.in = in_nhwc4; a.w = w_stem; a.out = out; a.dy = nullptr; a.dw = nullptr;
+  int rc = stem_args(a, N, Hin, Win, Hout, Wout);
+  if (rc != ISIC_OK) return rc;
+  const int grid = a.total_tiles < 1024 ? a.total_tiles : 1024;
+  hipLaunchKernelGGL(conv_stem_fwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), a);
+  return isic_launch_status();
+}
+
+int isic_conv_stem_wgrad_bf16(const uint16_t* in_nhwc4, const uint16_t* dy, float* dw, int N, int Hin, int Win,
+                              int Hout, int Wout, void* stream) {
+  ISIC_CHECK_ARG(in_nhwc4 && dy && dw && N > 0 && Hin > 0 && Win > 0);
+  StemArgs a;
+  a.in = in_nhwc4; a.w = nullptr; a.out = nullptr; a.dy = dy; a.dw = dw;
+  int rc = stem_args(a, N, Hin, Win, Hout, Wout);
+  if (rc != ISIC_OK) return rc;
+  const int grid = a.total_tiles < 512 ? a.total_tiles : 512;
+  hipLaunchKernelGGL(conv_stem_wgrad_kernel, dim3(grid), dim3(256), 0, as_stream(stream), a);
+  return isic_launch_status();
+}
+
+int isic_conv_stem_pack_bf16(const float* w_krsc, uint16_t* w_stem, void* stream) {
+  ISIC_CHECK_ARG(w_krsc && w_stem);
+  hipLaunchKernelGGL(stem_pack_kernel, dim3(ceil_div(64 * 224, 256)), dim3(256), 0, as_stream(stream), w_krsc, w_stem);
+  return isic_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,442 @@
+// HBM-bound companion kernels of the conv encoder (gfx950), NHWC bf16, 16-byte vector
+// accesses (8 channels per lane): BatchNorm2d training-mode statistics / apply / backward,
+// 3x3/2 max-pool, global average pool, layout packing, gradient joins.
+//
+// The reference has no counterpart (its encoder is an un-vendored ConvMAE, save_latent.py:42-60);
+// these implement the ResNet-18 named by BASELINE.json configs[1] with torchvision semantics
+// (BatchNorm2d eps 1e-5, momentum 0.1, biased variance for normalisation, unbiased for the running
+// estimate; MaxPool2d(3, 2, 1) with first-maximum tie breaking; AdaptiveAvgPool2d(1)).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const u32x4 v, float (&f)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(v[i] << 16);
+    f[2 * i + 1] = __uint_as_float(v[i] & 0xFFFF0000u);
+  }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    v[i] = (unsigned)f32_to_bf16_bits(f[2 * i]) | ((unsigned)f32_to_bf16_bits(f[2 * i + 1]) << 16);
+  return v;
+}
+
+// ---------------------------------------------------------------- BatchNorm statistics
+// thread -> channel group cg = tid % (C/8), row lane rl = tid / (C/8); per-thread fp32 partials over
+// a grid-strided set of rows, LDS tree over the rows-lanes of the block, fp64 atomics to global.
+template <int NACC>
+__device__ __forceinline__ void block_reduce_to_global(float (&acc)[NACC][8], int C, double* const (&dst)[NACC]) {
+  __shared__ float red[256 * 8];
+  const int tid = threadIdx.x, cgs = C >> 3, cg = tid % cgs, rl = tid / cgs, rls = 256 / cgs;
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[(rl * cgs + cg) * 8 + j] = acc[a][j];
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+      // channel c: group c>>3, element c&7
+      double s = 0.0;
+      for (int r = 0; r < rls; ++r) s += (double)red[(r * cgs + (c >> 3)) * 8 + (c & 7)];
+      atomicAdd(dst[a] + c, s);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const unsigned short* __restrict__ x, int64_t rows, int C,
+                                                        double* __restrict__ sum, double* __restrict__ sumsq) {
+  const int tid = threadIdx.x, cgs = C >> 3, cg = tid % cgs, rl = tid / cgs, rls = 256 / cgs;
+  float acc[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; }
+  for (int64_t r = (int64_t)blockIdx.x * rls + rl; r < rows; r += (int64_t)gridDim.x * rls) {
+    float f[8];
+    unpack8(*reinterpret_cast<const u32x4*>(x + r * C + cg * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { acc[0][j] += f[j]; acc[1][j] += f[j] * f[j]; }
+  }
+  double* const dst[2] = {sum, sumsq};
+  block_reduce_to_global<2>(acc, C, dst);
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sum, const double* __restrict__ sumsq, int64_t rows,
+                                   int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double n = (double)rows;
+  const double mean = sum[c] / n;
+  double var = sumsq[c] / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * rstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  mean_o[c] = (float)mean;
+  rstd_o[c] = rstd;
+  if (running_mean) {
+    const double unbiased = rows > 1 ? var * n / (n - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps, int C,
+                                      float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(rv[c] + eps);
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __restrict__ x,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ shift,
+                                                        const unsigned short* __restrict__ residual,
+                                                        unsigned short* __restrict__ y, int64_t nvec, int C, int relu) {
+  const int cgs = C >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % cgs);
+    float f[8], rsd[8];
+    unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), f);
+    if (residual) unpack8(*reinterpret_cast<const u32x4*>(residual + i * 8), rsd);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = f[j] * scale[cg * 8 + j] + shift[cg * 8 + j];
+      if (residual) v += rsd[j];
+      if (relu) v = fmaxf(v, 0.f);
+      f[j] = v;
+    }
+    *reinterpret_cast<u32x4*>(y + i * 8) = pack8(f);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned short* __restrict__ dy,
+                                                             const unsigned short* __restrict__ x,
+                                                             const unsigned short* __restrict__ y,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, int64_t rows, int C,
+                                                             int relu, double* __restrict__ dgamma,
+                                                             double* __restrict__ dbeta) {
+  const int tid = threadIdx.x, cgs = C >> 3, cg = tid % cgs, rl = tid / cgs, rls = 256 / cgs;
+  float acc[2][8], mu[8], rs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; mu[j] = mean[cg * 8 + j]; rs[j] = rstd[cg * 8 + j]; }
+  for (int64_t r = (int64_t)blockIdx.x * rls + rl; r < rows; r += (int64_t)gridDim.x * rls) {
+    float g[8], xv[8], yv[8];
+    unpack8(*reinterpret_cast<const u32x4*>(dy + r * C + cg * 8), g);
+    unpack8(*reinterpret_cast<const u32x4*>(x + r * C + cg * 8), xv);
+    if (relu) unpack8(*reinterpret_cast<const u32x4*>(y + r * C + cg * 8), yv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float dz = (relu && !(yv[j] > 0.f)) ? 0.f : g[j];
+      acc[0][j] += dz * ((xv[j] - mu[j]) * rs[j]);
+      acc[1][j] += dz;
+    }
+  }
+  double* const dst[2] = {dgamma, dbeta};
+  block_reduce_to_global<2>(acc, C, dst);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x, const unsigned short* __restrict__ y,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+    const double* __restrict__ dgamma, const double* __restrict__ dbeta, int64_t rows, int C, int relu,
+    unsigned short* __restrict__ dx, unsigned short* __restrict__ d_residual, float* __restrict__ dgamma_f32,
+    float* __restrict__ dbeta_f32) {
+  const int cgs = C >> 3;
+  const int64_t nvec = rows * cgs;
+  const float inv_rows = 1.f / (float)rows;
+  if (blockIdx.x == 0 && dgamma_f32) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      dgamma_f32[c] += (float)dgamma[c];
+      dbeta_f32[c] += (float)dbeta[c];
+    }
+  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % cgs);
+    float g[8], xv[8], yv[8], o[8];
+    unpack8(*reinterpret_cast<const u32x4*>(dy + i * 8), g);
+    unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), xv);
+    if (relu) unpack8(*reinterpret_cast<const u32x4*>(y + i * 8), yv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cg * 8 + j;
+      const float dz = (relu && !(yv[j] > 0.f)) ? 0.f : g[j];
+      g[j] = dz;
+      const float xh = (xv[j] - mean[c]) * rstd[c];
+      o[j] = gamma[c] * rstd[c] * (dz - (float)dbeta[c] * inv_rows - xh * ((float)dgamma[c] * inv_rows));
+    }
+    *reinterpret_cast<u32x4*>(dx + i * 8) = pack8(o);
+    if (d_residual) *reinterpret_cast<u32x4*>(d_residual + i * 8) = pack8(g);
+  }
+}
+
+// ---------------------------------------------------------------- pooling
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const unsigned short* __restrict__ x,
+                                                           unsigned short* __restrict__ y,
+                                                           unsigned char* __restrict__ argmax, int N, int H, int W,
+                                                           int C, int Ho, int Wo) {
+  const int cgs = C >> 3;
+  const int64_t nvec = (int64_t)N * Ho * Wo * cgs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % cgs);
+    int64_t t = i / cgs;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float best[8];
+    unsigned char bi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hi = ho * 2 - 1 + kh;
+      if (hi < 0 || hi >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int wi = wo * 2 - 1 + kw;
+        if (wi < 0 || wi >= W) continue;
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4*>(x + (((int64_t)n * H + hi) * W + wi) * C + cg * 8), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (f[j] > best[j]) { best[j] = f[j]; bi[j] = (unsigned char)(kh * 3 + kw); }  // first maximum wins
+      }
+    }
+    *reinterpret_cast<u32x4*>(y + i * 8) = pack8(best);
+    if (argmax) {
+      u32x2 p;
+      p[0] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | ((unsigned)bi[3] << 24);
+      p[1] = bi[4] | (bi[5] << 8) | (bi[6] << 16) | ((unsigned)bi[7] << 24);
+      *reinterpret_cast<u32x2*>(argmax + i * 8) = p;
+    }
+  }
+}
+
+// gather form: each input pixel looks at the <= 2x2 outputs whose window covers it
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* __restrict__ argmax,
+                                                           const unsigned short* __restrict__ dy,
+                                                           unsigned short* __restrict__ dx, int N, int H, int W, int C,
+                                                           int Ho, int Wo) {
+  const int cgs = C >> 3;
+  const int64_t nvec = (int64_t)N * H * W * cgs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % cgs);
+    int64_t t = i / cgs;
+    const int wi = (int)(t % W); t /= W;
+    const int hi = (int)(t % H);
+    const int n = (int)(t / H);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    // outputs ho with ho*2-1 <= hi <= ho*2+1  ->  ho in [ceil((hi-1)/2), floor((hi+1)/2)]
+    const int ho_lo = hi >> 1, ho_hi = (hi + 1) >> 1;
+    const int wo_lo = (wi) >> 1, wo_hi = (wi + 1) >> 1;
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+      if (ho >= Ho) continue;
+      const int kh = hi - (ho * 2 - 1);
+      if (kh < 0 || kh > 2) continue;
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        if (wo >= Wo) continue;
+        const int kw = wi - (wo * 2 - 1);
+        if (kw < 0 || kw > 2) continue;
+        const int64_t o = (((int64_t)n * Ho + ho) * Wo + wo) * C + cg * 8;
+        const u32x2 am = *reinterpret_cast<const u32x2*>(argmax + o);
+        float g[8];
+        unpack8(*reinterpret_cast<const u32x4*>(dy + o), g);
+        const unsigned code = (unsigned)(kh * 3 + kw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned b = (am[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+          if (b == code) acc[j] += g[j];
+        }
+      }
+    }
+    *reinterpret_cast<u32x4*>(dx + i * 8) = pack8(acc);
+  }
+}
+
+// one block per (image, 64-channel group): 4 waves stride the pixels
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const unsigned short* __restrict__ x, float* __restrict__ y,
+                                                           int HW, int C) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x, c = blockIdx.y * 64 + lane;
+  float s = 0.f;
+  if (c < C)
+    for (int p = wave; p < HW; p += 4) s += bf16_bits_to_f32(x[((int64_t)n * HW + p) * C + c]);
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && c < C)
+    y[(int64_t)n * C + c] = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) / (float)HW;
+}
+
+__global__ void avgpool_bwd_kernel(const float* __restrict__ dy, unsigned short* __restrict__ dx, int64_t total,
+                                   int HW, int C) {
+  const float inv = 1.f / (float)HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t n = i / ((int64_t)HW * C);
+    dx[i] = f32_to_bf16_bits(dy[n * C + c] * inv);
+  }
+}
+
+__global__ void add_bf16_kernel(unsigned short* __restrict__ a, const unsigned short* __restrict__ b, int64_t nvec) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    float fa[8], fb[8];
+    unpack8(*reinterpret_cast<const u32x4*>(a + i * 8), fa);
+    unpack8(*reinterpret_cast<const u32x4*>(b + i * 8), fb);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fa[j] += fb[j];
+    *reinterpret_cast<u32x4*>(a + i * 8) = pack8(fa);
+  }
+}
+
+// NCHW (fp32 or bf16) -> NHWC with C padded to 4, bf16.  One thread per output pixel.
+__global__ void nchw_to_nhwc4_kernel(const void* __restrict__ in, int in_is_bf16, unsigned short* __restrict__ out,
+                                     int64_t npix_total, int C, int64_t HW) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix_total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / HW, p = i - n * HW;
+    unsigned short v[4] = {0, 0, 0, 0};
+    for (int c = 0; c < C && c < 4; ++c) {
+      const int64_t src = (n * C + c) * HW + p;
+      v[c] = in_is_bf16 ? reinterpret_cast<const unsigned short*>(in)[src]
+                        : f32_to_bf16_bits(reinterpret_cast<const float*>(in)[src]);
+    }
+    u32x2 o;
+    o[0] = v[0] | ((unsigned)v[1] << 16);
+    o[1] = v[2] | ((unsigned)v[3] << 16);
+    *reinterpret_cast<u32x2*>(out + i * 4) = o;
+  }
+}
+
+inline int grid_for(int64_t n, int block, int cap = 8192) {
+  int64_t g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+inline bool bn_c_ok(int C) { return C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int isic_bn_stats_bf16(const uint16_t* x, int64_t rows, int C, double* sum, double* sumsq, void* stream) {
+  ISIC_CHECK_ARG(x && sum && sumsq && rows > 0 && C > 0);
+  if (!bn_c_ok(C)) return ISIC_ERR_UNSUPPORTED;
+  const int rls = 256 / (C / 8);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(rows, rls * 8, 2048)), dim3(256), 0, as_stream(stream), x, rows, C,
+                     sum, sumsq);
+  return isic_launch_status();
+}
+
+int isic_bn_finalize(const double* sum, const double* sumsq, int64_t rows, int C, const float* gamma,
+                     const float* beta, float eps, float momentum, float* scale, float* shift, float* mean,
+                     float* rstd, float* running_mean, float* running_var, void* stream) {
+  ISIC_CHECK_ARG(sum && sumsq && gamma && beta && scale && shift && mean && rstd && rows > 0 && C > 0);
+  ISIC_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, as_stream(stream), sum, sumsq, rows, C,
+                     gamma, beta, eps, momentum, scale, shift, mean, rstd, running_mean, running_var);
+  return isic_launch_status();
+}
+
+int isic_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                        float eps, int C, float* scale, float* shift, void* stream) {
+  ISIC_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && C > 0);
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, as_stream(stream), gamma, beta,
+                     running_mean, running_var, eps, C, scale, shift);
+  return isic_launch_status();
+}
+
+int isic_bn_apply_bf16(const uint16_t* x, const float* scale, const float* shift, const uint16_t* residual,
+                       uint16_t* y, int64_t rows, int C, int relu, void* stream) {
+  ISIC_CHECK_ARG(x && scale && shift && y && rows > 0 && C > 0 && C % 8 == 0);
+  const int64_t nvec = rows * (C / 8);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), x, scale, shift,
+                     residual, y, nvec, C, relu);
+  return isic_launch_status();
+}
+
+int isic_bn_bwd_reduce_bf16(const uint16_t* dy, const uint16_t* x, const uint16_t* y, const float* mean,
+                            const float* rstd, int64_t rows, int C, int relu, double* dgamma, double* dbeta,
+                            void* stream) {
+  ISIC_CHECK_ARG(dy && x && mean && rstd && dgamma && dbeta && rows > 0 && C > 0);
+  ISIC_CHECK_ARG(!relu || y);
+  if (!bn_c_ok(C)) return ISIC_ERR_UNSUPPORTED;
+  const int rls = 256 / (C / 8);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid_for(rows, rls * 8, 2048)), dim3(256), 0, as_stream(stream), dy, x,
+                     y, mean, rstd, rows, C, relu, dgamma, dbeta);
+  return isic_launch_status();
+}
+
+int isic_bn_bwd_apply_bf16(const uint16_t* dy, const uint16_t* x, const uint16_t* y, const float* mean,
+                           const float* rstd, const float* gamma, const double* dgamma, const double* dbeta,
+                           int64_t rows, int C, int relu, uint16_t* dx, uint16_t* d_residual, float* dgamma_f32,
+                           float* dbeta_f32, void* stream) {
+  ISIC_CHECK_ARG(dy && x && mean && rstd && gamma && dgamma && dbeta && dx && rows > 0 && C > 0 && C % 8 == 0);
+  ISIC_CHECK_ARG(!relu || y);
+  ISIC_CHECK_ARG((dgamma_f32 == nullptr) == (dbeta_f32 == nullptr));
+  const int64_t nvec = rows * (C / 8);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), dy, x, y, mean,
+                     rstd, gamma, dgamma, dbeta, rows, C, relu, dx, d_residual, dgamma_f32, dbeta_f32);
+  return isic_launch_status();
+}
+
+int isic_maxpool3x3s2_fwd_bf16(const uint16_t* x, uint16_t* y, uint8_t* argmax, int N, int H, int W, int C, int Ho,
+                               int Wo, void* stream) {
+  ISIC_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0);
+  ISIC_CHECK_ARG(Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1);
+  const int64_t nvec = (int64_t)N * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), x, y, argmax, N, H,
+                     W, C, Ho, Wo);
+  return isic_launch_status();
+}
+
+int isic_maxpool3x3s2_bwd_bf16(const uint8_t* argmax, const uint16_t* dy, uint16_t* dx, int N, int H, int W, int C,
+                               int Ho, int Wo, void* stream) {
+  ISIC_CHECK_ARG(argmax && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0);
+  const int64_t nvec = (int64_t)N * H * W * (C / 8);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), argmax, dy, dx, N,
+                     H, W, C, Ho, Wo);
+  return isic_launch_status();
+}
+
+int isic_avgpool_fwd_bf16(const uint16_t* x, float* y, int N, int HW, int C, void* stream) {
+  ISIC_CHECK_ARG(x && y && N > 0 && HW > 0 && C > 0);
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(N, ceil_div(C, 64)), dim3(256), 0, as_stream(stream), x, y, HW, C);
+  return isic_launch_status();
+}
+
+int isic_avgpool_bwd_bf16(const float* dy, uint16_t* dx, int N, int HW, int C, void* stream) {
+  ISIC_CHECK_ARG(dy && dx && N > 0 && HW > 0 && C > 0);
+  const int64_t total = (int64_t)N * HW * C;
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), dy, dx, total, HW,
+                     C);
+  return isic_launch_status();
+}
+
+int isic_add_bf16(uint16_t* a, const uint16_t* b, int64_t n, void* stream) {
+  ISIC_CHECK_ARG(a && b && n >= 0 && n % 8 == 0);
+  if (n == 0) return ISIC_OK;
+  hipLaunchKernelGGL(add_bf16_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, as_stream(stream), a, b, n / 8);
+  return isic_launch_status();
+}
+
+int isic_nchw_to_nhwc4_bf16(const void* in, int in_is_bf16, uint16_t* out, int N, int C, int H, int W, void* stream) {
+  ISIC_CHECK_ARG(in && out && N > 0 && C > 0 && C <= 4 && H > 0 && W > 0);
+  const int64_t npix = (int64_t)N * H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(grid_for(npix, 256)), dim3(256), 0, as_stream(stream), in, in_is_bf16,
+                     out, npix, C, (int64_t)H * W);
+  return isic_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,339 @@
+"""ResNet-18 patch encoder on hand-written HIP kernels (bf16 MFMA, NHWC).
+
+The reference's patch encoder is an un-vendored, frozen ConvMAE run through torch
+(`save_latent.py:42-60`); ``BASELINE.json`` configs[1] names a ResNet-18 trained
+end-to-end instead.  This module owns the parameters (torchvision names, conv
+weights held as ``channels_last`` OIHW tensors == the kernels' [O][Kh][Kw][I]
+layout) and a hand-scheduled forward/backward over ``libisic_hip.so``: implicit-GEMM
+convolutions (forward + data gradient), transposing-LDS weight gradients,
+BatchNorm statistics/apply/backward, pooling.  torch only provides device memory
+and the autograd edge to the MIL head.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .lib import IsicHipError, call
+
+LAYERS = ((64, 1), (128, 2), (256, 2), (512, 2))
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+_BF16 = torch.bfloat16
+
+
+def _empty(shape, like, dtype=_BF16):
+    return torch.empty(shape, device=like.device, dtype=dtype)
+
+
+class _ConvSpec:
+    __slots__ = ("name", "cin", "cout", "k", "stride", "pad")
+
+    def __init__(self, name, cin, cout, k, stride, pad):
+        self.name, self.cin, self.cout, self.k, self.stride, self.pad = name, cin, cout, k, stride, pad
+
+
+class ResNet18Encoder(nn.Module):
+    """``forward(images[N,3,H,W]) -> features[N,512]`` (fp32), train-mode BatchNorm
+    statistics over the local batch."""
+
+    out_dim = 512
+
+    def __init__(self, in_ch=3):
+        super().__init__()
+        if in_ch > 4:
+            raise ValueError("stem kernel supports at most 4 input channels")
+        self.in_ch = in_ch
+        self.specs = {}
+
+        def conv(name, cin, cout, k, stride, pad):
+            w = torch.empty(cout, cin, k, k).contiguous(memory_format=torch.channels_last)
+            nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu")
+            self._register(name + ".weight", nn.Parameter(w))
+            self.specs[name] = _ConvSpec(name, cin, cout, k, stride, pad)
+
+        def bn(name, c):
+            self._register(name + ".weight", nn.Parameter(torch.ones(c)))
+            self._register(name + ".bias", nn.Parameter(torch.zeros(c)))
+            self._register(name + ".running_mean", torch.zeros(c), buffer=True)
+            self._register(name + ".running_var", torch.ones(c), buffer=True)
+            self._register(name + ".num_batches_tracked", torch.zeros((), dtype=torch.long), buffer=True)
+
+        conv("conv1", in_ch, 64, 7, 2, 3)
+        bn("bn1", 64)
+        inp = 64
+        self.blocks = []
+        for li, (planes, stride) in enumerate(LAYERS, start=1):
+            for b in range(2):
+                pre = f"layer{li}.{b}"
+                st = stride if b == 0 else 1
+                conv(f"{pre}.conv1", inp, planes, 3, st, 1)
+                bn(f"{pre}.bn1", planes)
+                conv(f"{pre}.conv2", planes, planes, 3, 1, 1)
+                bn(f"{pre}.bn2", planes)
+                ds = st != 1 or inp != planes
+                if ds:
+                    conv(f"{pre}.downsample.0", inp, planes, 1, st, 0)
+                    bn(f"{pre}.downsample.1", planes)
+                self.blocks.append((pre, ds))
+                inp = planes
+        self._wcache = {}      # conv name -> (w_fwd bf16, w_dgrad bf16)
+        self.grad_ready_hook = None   # callable(list_of_param_names) fired as gradients complete (DDP overlap)
+
+    # parameters are registered under dotted torchvision names via nested holder modules
+    def _register(self, dotted, tensor, buffer=False):
+        parts = dotted.split(".")
+        mod = self
+        for p in parts[:-1]:
+            if not hasattr(mod, p):
+                mod.add_module(p, nn.Module())
+            mod = getattr(mod, p)
+        if buffer:
+            mod.register_buffer(parts[-1], tensor)
+        else:
+            mod.register_parameter(parts[-1], tensor)
+
+    def _get(self, dotted):
+        mod = self
+        for p in dotted.split("."):
+            mod = getattr(mod, p)
+        return mod
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        # .to()/.cuda() must keep conv weights in channels_last memory (= [O][Kh][Kw][I])
+        for name in self.specs:
+            p = self._get(name + ".weight")
+            if not p.data.is_contiguous(memory_format=torch.channels_last):
+                p.data = p.data.contiguous(memory_format=torch.channels_last)
+        self._wcache = {}
+        return out
+
+    # ------------------------------------------------------------------ weights in kernel layouts
+    def prepare_weights(self):
+        """fp32 master weights -> bf16 kernel layouts (forward [O][Kh][Kw][I], data-gradient
+        [I][Kh][Kw][O] flipped, packed stem).  Run once per forward: the optimizer updates the
+        master copy through raw pointers, so no version counter can be trusted."""
+        for name, sp in self.specs.items():
+            p = self._get(name + ".weight")
+            if not p.is_cuda:
+                raise IsicHipError("ResNet18Encoder runs on the MI355X only (no CPU fallback)")
+            if not p.data.is_contiguous(memory_format=torch.channels_last):
+                p.data = p.data.contiguous(memory_format=torch.channels_last)
+            ent = self._wcache.get(name)
+            if name == "conv1":
+                ws = ent[0] if ent else torch.empty(64 * 7 * 8 * 4, device=p.device, dtype=_BF16)
+                call("isic_conv_stem_pack_bf16", p.data, ws)
+                self._wcache[name] = (ws, None)
+            else:
+                n = sp.cout * sp.cin * sp.k * sp.k
+                wf = ent[0] if ent else torch.empty(n, device=p.device, dtype=_BF16)
+                wd = ent[1] if ent else torch.empty(n, device=p.device, dtype=_BF16)
+                call("isic_conv_weight_prep_bf16", p.data, wf, wd, sp.cout, sp.cin, sp.k, sp.k)
+                self._wcache[name] = (wf, wd)
+
+    def _weights(self, name, need_dgrad):
+        return self._wcache[name]
+
+    # ------------------------------------------------------------------ primitive launches
+    def _conv_fwd(self, x, name):
+        sp = self.specs[name]
+        N, H, W, C = x.shape
+        Ho = (H + 2 * sp.pad - sp.k) // sp.stride + 1
+        Wo = (W + 2 * sp.pad - sp.k) // sp.stride + 1
+        wf, _ = self._weights(name, False)
+        out = _empty((N, Ho, Wo, sp.cout), x)
+        call("isic_conv2d_igemm_bf16", x, wf, out, N, H, W, C, Ho, Wo, sp.cout, sp.k, sp.k, sp.stride, 1, sp.pad)
+        return out
+
+    def _conv_dgrad(self, dy, name, in_shape):
+        sp = self.specs[name]
+        N, H, W, C = in_shape
+        _, Ho, Wo, Co = dy.shape
+        _, wd = self._weights(name, True)
+        dx = _empty(in_shape, dy)
+        call("isic_conv2d_igemm_bf16", dy, wd, dx, N, Ho, Wo, Co, H, W, C, sp.k, sp.k, 1, sp.stride, sp.k - 1 - sp.pad)
+        return dx
+
+    def _grad_buffer(self, p):
+        if p.grad is None:
+            p.grad = torch.zeros_like(p.data, memory_format=torch.preserve_format)
+        return p.grad
+
+    def _conv_wgrad(self, x, dy, name):
+        sp = self.specs[name]
+        p = self._get(name + ".weight")
+        g = self._grad_buffer(p)
+        if not g.is_contiguous(memory_format=torch.channels_last):
+            raise IsicHipError(f"{name}.weight.grad must be channels_last ([O][Kh][Kw][I] memory)")
+        N, H, W, C = x.shape
+        _, Ho, Wo, Co = dy.shape
+        chunk = max(1, ((1 << 24) - 1) // (Ho * Wo))
+        for n0 in range(0, N, chunk):
+            n1 = min(N, n0 + chunk)
+            call("isic_conv2d_wgrad_bf16", x[n0:n1], dy[n0:n1], g, n1 - n0, H, W, C, Ho, Wo, Co, sp.k, sp.k,
+                 sp.stride, sp.pad)
+
+    def _bn_fwd(self, c, name, relu, residual=None):
+        N, H, W, C = c.shape
+        rows = N * H * W
+        gamma, beta = self._get(name + ".weight"), self._get(name + ".bias")
+        dev = c.device
+        scale = torch.empty(C, device=dev, dtype=torch.float32)
+        shift = torch.empty(C, device=dev, dtype=torch.float32)
+        mean = rstd = None
+        if self.training:
+            acc = torch.zeros(2, C, device=dev, dtype=torch.float64)
+            mean = torch.empty(C, device=dev, dtype=torch.float32)
+            rstd = torch.empty(C, device=dev, dtype=torch.float32)
+            call("isic_bn_stats_bf16", c, rows, C, acc[0], acc[1])
+            call("isic_bn_finalize", acc[0], acc[1], rows, C, gamma.data, beta.data, BN_EPS, BN_MOMENTUM, scale, shift,
+                 mean, rstd, self._get(name + ".running_mean"), self._get(name + ".running_var"))
+        else:
+            call("isic_bn_eval_affine", gamma.data, beta.data, self._get(name + ".running_mean"),
+                 self._get(name + ".running_var"), BN_EPS, C, scale, shift)
+        y = _empty(c.shape, c)
+        call("isic_bn_apply_bf16", c, scale, shift, residual, y, rows, C, int(relu))
+        return y, mean, rstd
+
+    def _bn_bwd(self, dy, c, y, mean, rstd, name, relu, want_residual):
+        N, H, W, C = c.shape
+        rows = N * H * W
+        gamma, beta = self._get(name + ".weight"), self._get(name + ".bias")
+        acc = torch.zeros(2, C, device=c.device, dtype=torch.float64)
+        call("isic_bn_bwd_reduce_bf16", dy, c, y, mean, rstd, rows, C, int(relu), acc[0], acc[1])
+        dx = _empty(c.shape, c)
+        dres = _empty(c.shape, c) if want_residual else None
+        call("isic_bn_bwd_apply_bf16", dy, c, y, mean, rstd, gamma.data, acc[0], acc[1], rows, C, int(relu), dx, dres,
+             self._grad_buffer(gamma), self._grad_buffer(beta))
+        return dx, dres
+
+    def _fire(self, names):
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(names)
+
+    # ------------------------------------------------------------------ forward / backward
+    def pack_input(self, images):
+        """NCHW fp32/bf16 images -> NHWC bf16 with C padded to 4."""
+        if images.dim() != 4 or images.shape[1] != self.in_ch:
+            raise ValueError(f"expected images[N,{self.in_ch},H,W], got {tuple(images.shape)}")
+        if not images.is_cuda:
+            raise IsicHipError("ResNet18Encoder runs on the MI355X only (no CPU fallback)")
+        if images.dtype not in (torch.float32, _BF16):
+            images = images.float()
+        images = images.contiguous()
+        N, C, H, W = images.shape
+        out = torch.empty((N, H, W, 4), device=images.device, dtype=_BF16)
+        call("isic_nchw_to_nhwc4_bf16", images, int(images.dtype == _BF16), out, N, C, H, W)
+        return out
+
+    def run_forward(self, images, save):
+        """Returns (features[N,512] fp32, tape).  ``save=False`` drops everything not
+        needed (inference)."""
+        self.prepare_weights()
+        x0 = self.pack_input(images)
+        N, H, W, _ = x0.shape
+        Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        ws, _ = self._weights("conv1", False)
+        c = _empty((N, Ho, Wo, 64), x0)
+        call("isic_conv_stem_fwd_bf16", x0, ws, c, N, H, W, Ho, Wo)
+        y, m, r = self._bn_fwd(c, "bn1", True)
+        Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
+        p = _empty((N, Hp, Wp, 64), y)
+        am = torch.empty((N, Hp, Wp, 64), device=y.device, dtype=torch.uint8) if save else None
+        call("isic_maxpool3x3s2_fwd_bf16", y, p, am, N, Ho, Wo, 64, Hp, Wp)
+        tape = {"x0": x0, "stem": (c, y, m, r, am, (N, Ho, Wo, 64)), "blocks": []} if save else None
+        x = p
+        for pre, ds in self.blocks:
+            idn, cd, md, rd = x, None, None, None
+            if ds:
+                cd = self._conv_fwd(x, f"{pre}.downsample.0")
+                idn, md, rd = self._bn_fwd(cd, f"{pre}.downsample.1", False)
+            c1 = self._conv_fwd(x, f"{pre}.conv1")
+            a1, m1, r1 = self._bn_fwd(c1, f"{pre}.bn1", True)
+            c2 = self._conv_fwd(a1, f"{pre}.conv2")
+            out, m2, r2 = self._bn_fwd(c2, f"{pre}.bn2", True, residual=idn)
+            if save:
+                tape["blocks"].append((x, c1, a1, m1, r1, c2, out, m2, r2, cd, md, rd))
+            x = out
+        N, Hf, Wf, Cf = x.shape
+        feat = torch.empty((N, Cf), device=x.device, dtype=torch.float32)
+        call("isic_avgpool_fwd_bf16", x, feat, N, Hf * Wf, Cf)
+        if save:
+            tape["final_shape"] = (N, Hf, Wf, Cf)
+            if self.training:
+                for name in self._bn_names():
+                    self._get(name + ".num_batches_tracked").add_(1)
+        return feat, tape
+
+    def _bn_names(self):
+        names = ["bn1"]
+        for pre, ds in self.blocks:
+            names += [f"{pre}.bn1", f"{pre}.bn2"] + ([f"{pre}.downsample.1"] if ds else [])
+        return names
+
+    def run_backward(self, tape, dfeat):
+        """Accumulates every parameter gradient (into ``param.grad``) from d loss / d features."""
+        if not self.training:
+            raise IsicHipError("encoder backward needs train() mode (batch-statistics BatchNorm)")
+        N, Hf, Wf, Cf = tape["final_shape"]
+        g = torch.empty((N, Hf, Wf, Cf), device=dfeat.device, dtype=_BF16)
+        call("isic_avgpool_bwd_bf16", dfeat.float().contiguous(), g, N, Hf * Wf, Cf)
+        for (pre, ds), saved in zip(reversed(self.blocks), reversed(tape["blocks"])):
+            x, c1, a1, m1, r1, c2, out, m2, r2, cd, md, rd = saved
+            dc2, dres = self._bn_bwd(g, c2, out, m2, r2, f"{pre}.bn2", True, True)
+            self._conv_wgrad(a1, dc2, f"{pre}.conv2")
+            da1 = self._conv_dgrad(dc2, f"{pre}.conv2", tuple(a1.shape))
+            del dc2
+            dc1, _ = self._bn_bwd(da1, c1, a1, m1, r1, f"{pre}.bn1", True, False)
+            del da1
+            self._conv_wgrad(x, dc1, f"{pre}.conv1")
+            dx = self._conv_dgrad(dc1, f"{pre}.conv1", tuple(x.shape))
+            del dc1
+            names = [f"{pre}.conv2.weight", f"{pre}.bn2.weight", f"{pre}.bn2.bias", f"{pre}.conv1.weight",
+                     f"{pre}.bn1.weight", f"{pre}.bn1.bias"]
+            if ds:
+                dcd, _ = self._bn_bwd(dres, cd, None, md, rd, f"{pre}.downsample.1", False, False)
+                self._conv_wgrad(x, dcd, f"{pre}.downsample.0")
+                dx2 = self._conv_dgrad(dcd, f"{pre}.downsample.0", tuple(x.shape))
+                call("isic_add_bf16", dx, dx2, dx.numel())
+                names += [f"{pre}.downsample.0.weight", f"{pre}.downsample.1.weight", f"{pre}.downsample.1.bias"]
+            else:
+                call("isic_add_bf16", dx, dres, dx.numel())
+            g = dx
+            self._fire(names)
+        c, y, m, r, am, yshape = tape["stem"]
+        N, Ho, Wo, _ = yshape
+        _, Hp, Wp, _ = g.shape
+        dy = _empty(yshape, g)
+        call("isic_maxpool3x3s2_bwd_bf16", am, g, dy, N, Ho, Wo, 64, Hp, Wp)
+        dc, _ = self._bn_bwd(dy, c, y, m, r, "bn1", True, False)
+        x0 = tape["x0"]
+        p = self._get("conv1.weight")
+        gw = self._grad_buffer(p)
+        call("isic_conv_stem_wgrad_bf16", x0, dc, gw, N, x0.shape[1], x0.shape[2], Ho, Wo)
+        self._fire(["conv1.weight", "bn1.weight", "bn1.bias"])
+
+    def forward(self, images):
+        if torch.is_grad_enabled() and self.training:
+            return _EncoderFn.apply(images, self, *[p for p in self.parameters()])
+        feat, _ = self.run_forward(images, save=False)
+        return feat
+
+
+class _EncoderFn(torch.autograd.Function):
+    """Autograd edge: features -> encoder parameter gradients.  The parameters are
+    passed as inputs only so that autograd schedules this node; their gradients are
+    accumulated in place by the kernels (``param.grad``), hence ``None`` is returned."""
+
+    @staticmethod
+    def forward(ctx, images, enc, *params):
+        feat, tape = enc.run_forward(images, save=True)
+        ctx.enc, ctx.tape = enc, tape
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        enc, tape = ctx.enc, ctx.tape
+        ctx.tape = None
+        enc.run_backward(tape, dfeat)
+        return (None, None) + tuple(None for _ in enc.parameters())

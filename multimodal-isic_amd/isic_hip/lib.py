@@ -104,8 +104,8 @@ def _ptr(x):
             return x.data_ptr() or None
         if not x.is_cuda:
             raise IsicHipError("libisic_hip expects device tensors (got a CPU tensor)")
-        if not x.is_contiguous():
-            raise IsicHipError("libisic_hip expects contiguous tensors")
+        if not (x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))):
+            raise IsicHipError("libisic_hip expects dense (contiguous or channels_last) tensors")
         return x.data_ptr()
     return int(x)
 

@@ -34,16 +34,17 @@ class FlatParams:
         self.data = torch.zeros(n, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
         for p, o in zip(self.params, self.offsets):
-            v = self.data[o:o + p.numel()].view_as(p)
+            # keep each tensor's own dense layout (conv weights are channels_last = [O][Kh][Kw][I])
+            v = torch.as_strided(self.data, p.shape, p.stride(), storage_offset=o)
             v.copy_(p.data)
             p.data = v
-            p.grad = self.grad[o:o + p.numel()].view_as(p)
+            p.grad = torch.as_strided(self.grad, p.shape, p.stride(), storage_offset=o)
 
     def zero_grad(self):
         self.grad.zero_()
         for p, o in zip(self.params, self.offsets):  # re-attach views if something replaced them
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
-                p.grad = self.grad[o:o + p.numel()].view_as(p)
+                p.grad = torch.as_strided(self.grad, p.shape, p.stride(), storage_offset=o)
 
 
 class _FlatAdamBase:

@@ -1,0 +1,251 @@
+"""GPU parity of the conv-encoder kernels (bf16 MFMA implicit GEMM, transposing-LDS
+weight gradient, BatchNorm, pooling) against plain torch fp32 references on
+bf16-rounded operands, and of the whole ResNet-18 against ``oracle/resnet.py``.
+
+Tolerances (stated per test): operands are exactly representable in bf16 on both
+sides and accumulation is fp32, so conv outputs differ from the fp32 reference only
+by the final rounding to bf16 (<= 2^-8 relative per element) and summation order."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import assert_close
+from oracle import formula, resnet
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def rb(t):
+    return t.bfloat16().float()
+
+
+def nhwc(t):  # NCHW fp32 -> NHWC bf16 on device
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV, BF)
+
+
+def from_nhwc(t):
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def krsc(w):  # OIHW fp32 -> [O][Kh][Kw][I] fp32 device (channels_last memory)
+    return w.to(DEV).contiguous(memory_format=torch.channels_last)
+
+
+def bf16_close(a, ref, what, extra_atol=0.0):
+    """|a - ref| <= 2^-7 |ref| + atol: one bf16 rounding of the fp32 result (2^-8) plus slack for
+    fp32 summation-order differences moving a value across a rounding boundary."""
+    a, ref = a.double(), ref.double()
+    tol = (2.0 ** -7) * ref.abs() + 2e-3 * ref.abs().max() * 2 ** -4 + extra_atol
+    bad = (a - ref).abs() > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max diff {float((a - ref).abs().max()):.4e}"
+
+
+CONV_CASES = [  # N, H, W, Cin, Cout, k, stride, pad
+    (2, 16, 16, 64, 64, 3, 1, 1),
+    (3, 10, 10, 64, 128, 3, 2, 1),     # M not a tile multiple
+    (3, 10, 10, 64, 128, 1, 2, 0),     # downsample
+    (2, 8, 8, 128, 128, 3, 1, 1),
+    (5, 7, 7, 256, 512, 3, 2, 1),
+    (1, 14, 14, 512, 512, 3, 1, 1),
+    (4, 9, 11, 128, 64, 3, 1, 1),      # non-square, Cout 64 path
+]
+
+
+def _conv_data(case, seed):
+    N, H, W, Ci, Co, k, s, p = case
+    g = torch.Generator().manual_seed(seed)
+    x = rb(torch.randn(N, Ci, H, W, generator=g))
+    w = rb(torch.randn(Co, Ci, k, k, generator=g) / np.sqrt(Ci * k * k))
+    return x, w
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward(case):
+    from isic_hip.lib import call
+    N, H, W, Ci, Co, k, s, p = case
+    x, w = _conv_data(case, 1)
+    ref = F.conv2d(x, w, None, s, p)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    wf = torch.empty(Co * Ci * k * k, device=DEV, dtype=BF)
+    wd = torch.empty_like(wf)
+    call("isic_conv_weight_prep_bf16", krsc(w), wf, wd, Co, Ci, k, k)
+    out = torch.empty(N, Ho, Wo, Co, device=DEV, dtype=BF)
+    call("isic_conv2d_igemm_bf16", nhwc(x), wf, out, N, H, W, Ci, Ho, Wo, Co, k, k, s, 1, p)
+    bf16_close(from_nhwc(out), ref, f"conv fwd {case}")
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_dgrad_and_wgrad(case):
+    from isic_hip.lib import call
+    N, H, W, Ci, Co, k, s, p = case
+    x, w = _conv_data(case, 2)
+    x.requires_grad_(True)
+    w.requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p)
+    dy = rb(torch.randn(y.shape, generator=torch.Generator().manual_seed(3)))
+    y.backward(dy)
+    Ho, Wo = y.shape[2], y.shape[3]
+    wf = torch.empty(Co * Ci * k * k, device=DEV, dtype=BF)
+    wd = torch.empty_like(wf)
+    call("isic_conv_weight_prep_bf16", krsc(w.detach()), wf, wd, Co, Ci, k, k)
+    dyd = nhwc(dy)
+    dx = torch.empty(N, H, W, Ci, device=DEV, dtype=BF)
+    call("isic_conv2d_igemm_bf16", dyd, wd, dx, N, Ho, Wo, Co, H, W, Ci, k, k, 1, s, k - 1 - p)
+    bf16_close(from_nhwc(dx), x.grad, f"conv dgrad {case}")
+    dw = torch.zeros(Co, Ci, k, k, device=DEV).contiguous(memory_format=torch.channels_last)
+    call("isic_conv2d_wgrad_bf16", nhwc(x.detach()), dyd, dw, N, H, W, Ci, Ho, Wo, Co, k, k, s, p)
+    # fp32 result of exactly-representable operands: summation order only
+    assert_close(dw.cpu(), w.grad, rtol=2e-4, atol=1e-5, what=f"conv wgrad {case}")
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32), (3, 20, 44), (1, 224, 224)])
+def test_stem_forward_and_wgrad(shape):
+    from isic_hip.lib import call
+    N, H, W = shape
+    g = torch.Generator().manual_seed(5)
+    x = rb(torch.randn(N, 3, H, W, generator=g)).requires_grad_(True)
+    w = rb(torch.randn(64, 3, 7, 7, generator=g) / np.sqrt(147.0)).requires_grad_(True)
+    y = F.conv2d(x, w, None, 2, 3)
+    dy = rb(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    Ho, Wo = y.shape[2], y.shape[3]
+    x4 = torch.empty(N, H, W, 4, device=DEV, dtype=BF)
+    call("isic_nchw_to_nhwc4_bf16", x.detach().to(DEV), 0, x4, N, 3, H, W)
+    ws = torch.empty(64 * 7 * 8 * 4, device=DEV, dtype=BF)
+    call("isic_conv_stem_pack_bf16", krsc(w.detach()), ws)
+    out = torch.empty(N, Ho, Wo, 64, device=DEV, dtype=BF)
+    call("isic_conv_stem_fwd_bf16", x4, ws, out, N, H, W, Ho, Wo)
+    bf16_close(from_nhwc(out), y.detach(), f"stem fwd {shape}")
+    dw = torch.zeros(64, 3, 7, 7, device=DEV).contiguous(memory_format=torch.channels_last)
+    call("isic_conv_stem_wgrad_bf16", x4, nhwc(dy), dw, N, H, W, Ho, Wo)
+    assert_close(dw.cpu(), w.grad, rtol=2e-4, atol=1e-5, what=f"stem wgrad {shape}")
+
+
+@pytest.mark.parametrize("C,relu,res", [(64, 1, 0), (128, 1, 1), (512, 0, 0), (256, 1, 1)])
+def test_batchnorm_forward_backward(C, relu, res):
+    from isic_hip.lib import call
+    N, H, W = 3, 6, 5
+    g = torch.Generator().manual_seed(7)
+    x = rb(torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    r = rb(torch.randn(N, C, H, W, generator=g)).requires_grad_(True) if res else None
+    rm, rv = torch.zeros(C), torch.ones(C)
+    y = F.batch_norm(x, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    if res:
+        y = y + r
+    if relu:
+        y = F.relu(y)
+    dy = rb(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    rows = N * H * W
+    xd = nhwc(x.detach())
+    acc = torch.zeros(2, C, device=DEV, dtype=torch.float64)
+    scale, shift, mean, rstd = (torch.empty(C, device=DEV) for _ in range(4))
+    rmd, rvd = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    call("isic_bn_stats_bf16", xd, rows, C, acc[0], acc[1])
+    call("isic_bn_finalize", acc[0], acc[1], rows, C, gamma.detach().to(DEV), beta.detach().to(DEV), 1e-5, 0.1, scale,
+         shift, mean, rstd, rmd, rvd)
+    assert_close(rmd.cpu(), rm, rtol=1e-5, atol=1e-6, what="running_mean")
+    assert_close(rvd.cpu(), rv, rtol=1e-5, atol=1e-6, what="running_var")
+    yd = torch.empty_like(xd)
+    call("isic_bn_apply_bf16", xd, scale, shift, nhwc(r.detach()) if res else None, yd, rows, C, relu)
+    bf16_close(from_nhwc(yd), y.detach(), "bn fwd")
+    acc2 = torch.zeros(2, C, device=DEV, dtype=torch.float64)
+    dyd = nhwc(dy)
+    call("isic_bn_bwd_reduce_bf16", dyd, xd, yd, mean, rstd, rows, C, relu, acc2[0], acc2[1])
+    dx = torch.empty_like(xd)
+    dres = torch.empty_like(xd) if res else None
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    call("isic_bn_bwd_apply_bf16", dyd, xd, yd, mean, rstd, gamma.detach().to(DEV), acc2[0], acc2[1], rows, C, relu,
+         dx, dres, dg, db)
+    # the ReLU mask comes from the bf16-rounded output: elements within one rounding of 0 may flip
+    assert_close(dg.cpu(), gamma.grad, rtol=2e-2, atol=2e-2, what="dgamma")
+    assert_close(db.cpu(), beta.grad, rtol=2e-2, atol=2e-2, what="dbeta")
+    d = (from_nhwc(dx) - x.grad).abs()
+    assert float(d.mean()) < 2e-2 * float(x.grad.abs().mean()) + 1e-4, "bn dx mean error"
+    if res:
+        d = (from_nhwc(dres) - r.grad).abs()
+        assert float((d > 1e-6).float().mean()) < 5e-3
+
+
+def test_pools():
+    from isic_hip.lib import call
+    N, C, H, W = 2, 64, 13, 16
+    g = torch.Generator().manual_seed(9)
+    x = F.relu(rb(torch.randn(N, C, H, W, generator=g))).requires_grad_(True)   # many exact ties at 0
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = rb(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    Ho, Wo = y.shape[2], y.shape[3]
+    xd = nhwc(x.detach())
+    yd = torch.empty(N, Ho, Wo, C, device=DEV, dtype=BF)
+    am = torch.empty(N, Ho, Wo, C, device=DEV, dtype=torch.uint8)
+    call("isic_maxpool3x3s2_fwd_bf16", xd, yd, am, N, H, W, C, Ho, Wo)
+    assert torch.equal(from_nhwc(yd), y.detach())
+    dx = torch.empty_like(xd)
+    call("isic_maxpool3x3s2_bwd_bf16", am, nhwc(dy), dx, N, H, W, C, Ho, Wo)
+    bf16_close(from_nhwc(dx), x.grad, "maxpool bwd")
+    f = torch.empty(N, C, device=DEV)
+    call("isic_avgpool_fwd_bf16", xd, f, N, H * W, C)
+    assert_close(f.cpu(), x.detach().mean(dim=(2, 3)), rtol=1e-5, atol=1e-6, what="avgpool")
+    dfe = torch.randn(N, C, generator=g)
+    dxa = torch.empty_like(xd)
+    call("isic_avgpool_bwd_bf16", dfe.to(DEV), dxa, N, H * W, C)
+    bf16_close(from_nhwc(dxa), (dfe / (H * W))[:, :, None, None].expand(N, C, H, W), "avgpool bwd")
+
+
+def _encoder_pair(seed=0):
+    from isic_hip.encoder import ResNet18Encoder
+    enc = ResNet18Encoder()
+    p = formula.formula_state_dict(resnet.resnet18_shapes(), gain=1.0)
+    sd = enc.state_dict()
+    for k, v in p.items():
+        sd[k] = v
+    enc.load_state_dict(sd)
+    return enc.to(DEV), p
+
+
+def test_resnet18_forward_matches_oracle():
+    """Whole encoder vs oracle/resnet.py with bf16 rounding emulated at the same
+    points.  Tolerance: 3 % of the feature scale (18 stacked bf16 roundings)."""
+    enc, p = _encoder_pair()
+    enc.train()
+    x = rb(formula.ftensor((4, 3, 64, 64), 1.0, 0.19, 0.3))
+    stats = {}
+    ref = resnet.resnet18_features(p, x, emulate_bf16=True, stats=stats)
+    feat = enc(x.to(DEV))
+    assert feat.shape == (4, 512)
+    scale = float(ref.abs().mean())
+    err = float((feat.detach().cpu() - ref).abs().mean())
+    assert err < 0.03 * scale, f"mean |diff| {err:.4e} vs feature scale {scale:.4e}"
+    # running statistics of the first BatchNorm follow torch semantics
+    m, v = stats["bn1"]
+    n = 4 * 32 * 32
+    assert_close(enc.bn1.running_mean.cpu(), 0.1 * m, rtol=2e-2, atol=1e-3, what="bn1.running_mean")
+    assert_close(enc.bn1.running_var.cpu(), 0.9 + 0.1 * v * n / (n - 1), rtol=2e-2, atol=1e-3, what="bn1.running_var")
+
+
+def test_resnet18_backward_matches_oracle():
+    """Parameter gradients of sum(features * g) vs autograd through the oracle.
+    Tolerance: relative L2 error per tensor < 8 % (bf16 activations AND bf16
+    activation gradients through 17 layers; the oracle emulates both)."""
+    enc, p = _encoder_pair()
+    enc.train()
+    x = rb(formula.ftensor((4, 3, 64, 64), 1.0, 0.19, 0.3))
+    gfeat = formula.ftensor((4, 512), 1.0, 0.23, 0.7)
+    q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ref = resnet.resnet18_features(q, x, emulate_bf16=True)
+    (ref * gfeat).sum().backward()
+    feat = enc(x.to(DEV))
+    (feat * gfeat.to(DEV)).sum().backward()
+    worst = 0.0
+    for k, prm in enc.named_parameters():
+        g, r = prm.grad.detach().cpu().double(), q[k].grad.double()
+        rel = float((g - r).norm() / (r.norm() + 1e-12))
+        worst = max(worst, rel)
+        assert rel < 0.08, f"{k}: relative L2 error {rel:.3e}"
+    print("worst relative L2 grad error", worst)

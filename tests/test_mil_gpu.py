@@ -107,8 +107,13 @@ def test_adamw_three_steps_golden():
         loss = ops.cross_entropy(out["bag_logits"].unsqueeze(0), y)
         loss.backward()
         opt.step()
-        assert abs(float(loss) - float(g[f"loss{s}"])) < 2e-5
+        assert abs(float(loss.detach()) - float(g[f"loss{s}"])) < 2e-5
         for k, v in m.state_dict().items():
+            if k == "attention.2.bias":
+                # softmax is shift invariant: d loss / d b3 == 0 analytically, so Adam's first steps
+                # (lr * g / (|g| + eps)) amplify pure rounding noise of either implementation.
+                assert float(m.attention[2].bias.grad.abs().max()) < 1e-6
+                continue
             assert_close(v, g[f"step{s}.{k}"], rtol=2e-5, atol=2e-7, what=f"step{s}.{k}")
 
 
