@@ -36,10 +36,10 @@ class ResNet18Encoder(nn.Module):
     """``forward(images[N,3,H,W]) -> features[N,512]`` (fp32), train-mode BatchNorm
     statistics over the local batch."""
 
-    out_dim = 512
-
-    def __init__(self, in_ch=3):
+    def __init__(self, in_ch=3, layers=LAYERS):
         super().__init__()
+        self.layers_cfg = tuple(layers)
+        self.out_dim = self.layers_cfg[-1][0]
         if in_ch > 4:
             raise ValueError("stem kernel supports at most 4 input channels")
         self.in_ch = in_ch
@@ -62,7 +62,7 @@ class ResNet18Encoder(nn.Module):
         bn("bn1", 64)
         inp = 64
         self.blocks = []
-        for li, (planes, stride) in enumerate(LAYERS, start=1):
+        for li, (planes, stride) in enumerate(self.layers_cfg, start=1):
             for b in range(2):
                 pre = f"layer{li}.{b}"
                 st = stride if b == 0 else 1

@@ -24,7 +24,7 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
 
-def resnet18_shapes(in_ch=3):
+def resnet18_shapes(in_ch=3, layers=LAYERS):
     s = OrderedDict()
 
     def bn(prefix, c):
@@ -34,7 +34,7 @@ def resnet18_shapes(in_ch=3):
     s["conv1.weight"] = (64, in_ch, 7, 7)
     bn("bn1", 64)
     inp = 64
-    for li, (planes, stride) in enumerate(LAYERS, start=1):
+    for li, (planes, stride) in enumerate(layers, start=1):
         for b in range(2):
             pre = f"layer{li}.{b}"
             st = stride if b == 0 else 1
@@ -73,8 +73,9 @@ def _bn_train(x, w, b, stats, name):
     return (x - mean[None, :, None, None]) * (inv * w)[None, :, None, None] + b[None, :, None, None]
 
 
-def resnet18_features(p, x, emulate_bf16=False, stats=None, taps=None):
-    """x[N,3,H,W] fp32 -> features[N,512] fp32 (train-mode BatchNorm)."""
+def resnet18_features(p, x, emulate_bf16=False, stats=None, taps=None, layers=LAYERS):
+    """x[N,3,H,W] fp32 -> features[N,512] fp32 (train-mode BatchNorm).  ``layers`` shortens the
+    network for well-conditioned tests (default: the four ResNet-18 stages)."""
     e = emulate_bf16
 
     def conv(t, name, stride, pad):
@@ -100,7 +101,7 @@ def resnet18_features(p, x, emulate_bf16=False, stats=None, taps=None):
     if taps is not None:
         taps["pool"] = t
     inp = 64
-    for li, (planes, stride) in enumerate(LAYERS, start=1):
+    for li, (planes, stride) in enumerate(layers, start=1):
         for b in range(2):
             pre = f"layer{li}.{b}"
             st = stride if b == 0 else 1

@@ -198,30 +198,54 @@ def test_pools():
     bf16_close(from_nhwc(dxa), (dfe / (H * W))[:, :, None, None].expand(N, C, H, W), "avgpool bwd")
 
 
-def _encoder_pair(seed=0):
+def _encoder_pair(seed=0, layers=resnet.LAYERS):
+    """Encoder with seeded He-normal conv weights (the init the module itself uses) and
+    non-trivial BatchNorm affine parameters, plus the same parameters as an oracle dict."""
     from isic_hip.encoder import ResNet18Encoder
-    enc = ResNet18Encoder()
-    p = formula.formula_state_dict(resnet.resnet18_shapes(), gain=1.0)
+    enc = ResNet18Encoder(layers=layers)
+    g = torch.Generator().manual_seed(100 + seed)
+    p = {}
+    for k, shp in resnet.resnet18_shapes(layers=layers).items():
+        if len(shp) == 4:
+            fan_out = shp[0] * shp[2] * shp[3]
+            p[k] = torch.randn(shp, generator=g) * float(np.sqrt(2.0 / fan_out))
+        elif k.endswith("weight"):
+            p[k] = 1.0 + 0.2 * torch.randn(shp, generator=g)
+        else:
+            p[k] = 0.1 * torch.randn(shp, generator=g)
     sd = enc.state_dict()
-    for k, v in p.items():
-        sd[k] = v
+    sd.update(p)
     enc.load_state_dict(sd)
     return enc.to(DEV), p
 
 
+def _stage_report(enc, tape, taps):
+    rep = {}
+    names = ["stem"] + [pre for pre, _ in enc.blocks]
+    outs = [tape["stem"][1]] + [b[6] for b in tape["blocks"]]
+    for n, o in zip(names, outs):
+        r = taps[n]
+        d = from_nhwc(o)
+        rep[n] = float((d - r).abs().mean() / (r.abs().mean() + 1e-12))
+    return rep
+
+
 def test_resnet18_forward_matches_oracle():
     """Whole encoder vs oracle/resnet.py with bf16 rounding emulated at the same
-    points.  Tolerance: 3 % of the feature scale (18 stacked bf16 roundings)."""
+    points.  Tolerance: mean |diff| < 3 % of the mean |feature| (18 stacked bf16
+    roundings, each 2^-9 relative on average, amplified by BatchNorm rescaling)."""
     enc, p = _encoder_pair()
     enc.train()
-    x = rb(formula.ftensor((4, 3, 64, 64), 1.0, 0.19, 0.3))
-    stats = {}
-    ref = resnet.resnet18_features(p, x, emulate_bf16=True, stats=stats)
-    feat = enc(x.to(DEV))
+    x = rb(torch.randn(4, 3, 64, 64, generator=torch.Generator().manual_seed(11)))
+    stats, taps = {}, {}
+    ref = resnet.resnet18_features(p, x, emulate_bf16=True, stats=stats, taps=taps)
+    feat, tape = enc.run_forward(x.to(DEV), save=True)
     assert feat.shape == (4, 512)
+    rep = _stage_report(enc, tape, taps)
+    print("per-stage relative mean error:", {k: f"{v:.2e}" for k, v in rep.items()})
     scale = float(ref.abs().mean())
     err = float((feat.detach().cpu() - ref).abs().mean())
-    assert err < 0.03 * scale, f"mean |diff| {err:.4e} vs feature scale {scale:.4e}"
+    assert err < 0.03 * scale, f"mean |diff| {err:.4e} vs feature scale {scale:.4e}; stages {rep}"
     # running statistics of the first BatchNorm follow torch semantics
     m, v = stats["bn1"]
     n = 4 * 32 * 32
@@ -229,23 +253,57 @@ def test_resnet18_forward_matches_oracle():
     assert_close(enc.bn1.running_var.cpu(), 0.9 + 0.1 * v * n / (n - 1), rtol=2e-2, atol=1e-3, what="bn1.running_var")
 
 
-def test_resnet18_backward_matches_oracle():
-    """Parameter gradients of sum(features * g) vs autograd through the oracle.
-    Tolerance: relative L2 error per tensor < 8 % (bf16 activations AND bf16
-    activation gradients through 17 layers; the oracle emulates both)."""
-    enc, p = _encoder_pair()
+def _grad_errors(layers, N, HW, dtype=torch.float32):
+    enc, p = _encoder_pair(layers=layers)
     enc.train()
-    x = rb(formula.ftensor((4, 3, 64, 64), 1.0, 0.19, 0.3))
-    gfeat = formula.ftensor((4, 512), 1.0, 0.23, 0.7)
-    q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
-    ref = resnet.resnet18_features(q, x, emulate_bf16=True)
-    (ref * gfeat).sum().backward()
+    x = rb(torch.randn(N, 3, HW, HW, generator=torch.Generator().manual_seed(11)))
+    gfeat = torch.randn(N, layers[-1][0], generator=torch.Generator().manual_seed(12))
+
+    def oracle_grads(dt):
+        q = {k: v.to(dt).clone().requires_grad_(True) for k, v in p.items()}
+        ref = resnet.resnet18_features(q, x.to(dt), emulate_bf16=True, layers=layers)
+        (ref * gfeat.to(dt)).sum().backward()
+        return {k: v.grad.double() for k, v in q.items()}
+
+    g32 = oracle_grads(torch.float32)
     feat = enc(x.to(DEV))
     (feat * gfeat.to(DEV)).sum().backward()
-    worst = 0.0
+    rep = {}
     for k, prm in enc.named_parameters():
-        g, r = prm.grad.detach().cpu().double(), q[k].grad.double()
-        rel = float((g - r).norm() / (r.norm() + 1e-12))
-        worst = max(worst, rel)
-        assert rel < 0.08, f"{k}: relative L2 error {rel:.3e}"
-    print("worst relative L2 grad error", worst)
+        g = prm.grad.detach().cpu().double()
+        rep[k] = (float((g - g32[k]).norm() / (g32[k].norm() + 1e-12)),
+                  float((g * g32[k]).sum() / (g.norm() * g32[k].norm() + 1e-30)))
+    return rep, g32, oracle_grads
+
+
+def test_encoder_backward_one_stage_tight():
+    """stem + max-pool + two basic blocks: shallow enough that bf16 rounding flips do not
+    compound (the oracle itself moves by 0.2 % between fp32 and fp64 accumulation here), so
+    every parameter gradient must match to 1.5 % relative L2."""
+    rep, _, _ = _grad_errors(((64, 1),), 6, 48)
+    print({k: f"{v[0]:.2e}" for k, v in rep.items()})
+    bad = {k: v for k, v in rep.items() if v[0] >= 0.015}
+    assert not bad, bad
+
+
+def test_encoder_backward_two_stage_downsample():
+    """adds a stride-2 stage with its 1x1 downsample branch.  The oracle's own self-noise
+    (fp32 vs fp64 accumulation) is 3 % here and the HIP path rounds the residual gradient join
+    to bf16 twice more per block than the oracle does: relative L2 < 12 % and cosine > 0.99."""
+    rep, _, _ = _grad_errors(((64, 1), (128, 2)), 6, 48)
+    print({k: f"{v[0]:.2e}" for k, v in rep.items()})
+    bad = {k: v for k, v in rep.items() if v[0] >= 0.12 or v[1] < 0.99}
+    assert not bad, bad
+
+
+def test_resnet18_backward_matches_oracle():
+    """Full ResNet-18.  17 stacked bf16 layers at random init are chaotic: the CPU oracle's own
+    gradients move by up to ~20 % (relative L2) when only its accumulation precision changes
+    (fp32 vs fp64, same bf16 rounding points).  The HIP gradients therefore have to (a) stay
+    within 2.5x of that self-noise per tensor and (b) point the same way (cosine > 0.9)."""
+    rep, g32, oracle_grads = _grad_errors(resnet.LAYERS, 4, 64)
+    g64 = oracle_grads(torch.float64)
+    noise = {k: float((g32[k] - g64[k]).norm() / (g64[k].norm() + 1e-12)) for k in g32}
+    print("HIP vs oracle / oracle self-noise:", {k: f"{rep[k][0]:.2e}/{noise[k]:.2e}" for k in rep})
+    bad = {k: (rep[k], noise[k]) for k in rep if rep[k][0] > 2.5 * max(noise[k], 0.02) or rep[k][1] < 0.9}
+    assert not bad, bad
