@@ -1,0 +1,231 @@
+"""Headline benchmark: bags/sec of the attention-MIL train step (fwd + bwd + AdamW, grad
+all-reduce when N > 1) on ISIC-shaped synthetic bags: 64 patches of 3x224x224 per bag +
+a 128-d radiomic vector, ResNet-18 patch encoder, bf16 MFMA convolutions.
+
+    python bench.py --gpus 1 --steps 8 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the repo instructions): whole-job bags/s with
+inputs resident in HBM, plus
+  "roofline":     dominant kernel (implicit-GEMM convolution) algorithmic FLOP/s, measured
+                  with HIP events around every launch of the timed region, vs the dense
+                  bf16 MFMA peak (2.5 PFLOP/s);
+  "cpu_baseline": the CPU oracle's per-bag training loop (reference loop shape,
+                  01_train_mil_teacher.py:235-246) timed on the host cores, rank 0, N = 1.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "multimodal-isic_amd"))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+WORKLOAD = ("ISIC-shaped attention-MIL: 256 bags x 64x224x224 patches + 128-d radiomics, "
+            "ResNet-18 encoder, bf16 (BASELINE.json configs[1])")
+
+
+def conv_flops(spec_args):
+    """Algorithmic FLOPs of one isic_conv2d_igemm_bf16 launch (2*M*Cout*K of the convolution it
+    implements; for a data-gradient launch that is the forward convolution's count)."""
+    (_in, _w, _out, N, Hin, Win, Cin, Hout, Wout, Cout, Kh, Kw, up, down, pad) = spec_args
+    if down == 1:      # forward: out pixels x Cout x (Kh*Kw*Cin)
+        return 2.0 * N * Hout * Wout * Cout * Kh * Kw * Cin
+    # dgrad with stride `down`: only 1/down^2 of the taps hit a real dY pixel
+    return 2.0 * N * Hout * Wout * Cout * Kh * Kw * Cin / (down * down)
+
+
+class KernelTimer:
+    """HIP-event timing of selected C-ABI launches on the stream they are launched on."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.records = []
+        self.active = False
+
+    def install(self):
+        from isic_hip import lib
+        orig = lib.call
+        timer = self
+
+        def timed_call(name, *args, stream=None):
+            if timer.active and name in timer.names:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = orig(name, *args, stream=stream)
+                e1.record()
+                timer.records.append((name, args[3:], e0, e1))
+                return rc
+            return orig(name, *args, stream=stream)
+
+        lib.call = timed_call
+        import isic_hip.encoder as enc
+        import isic_hip.ops as ops
+        enc.call = timed_call
+        ops.call = timed_call
+
+    def summary(self):
+        total_ms, total_flops, n = 0.0, 0.0, 0
+        for name, a, e0, e1 in self.records:
+            total_ms += e0.elapsed_time(e1)
+            total_flops += conv_flops((None, None, None) + tuple(a))
+            n += 1
+        return n, total_ms, total_flops
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--bags-per-step", type=int, default=8, help="bags per optimizer step PER GPU")
+    ap.add_argument("--patches", type=int, default=64)
+    ap.add_argument("--image-size", type=int, default=224)
+    ap.add_argument("--radiomics-dim", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from isic_hip import ddp, optim
+    from model import MultiModalMILNet
+
+    B, K, S, R, C = args.bags_per_step, args.patches, args.image_size, args.radiomics_dim, 7
+    torch.manual_seed(42)
+    model = MultiModalMILNet(hidden_dim=128, att_dim=64, dropout=0.5, radiomics_dim=R, num_classes=C).to(dev)
+    model.train()
+    model.set_dropout_state(seed=42, step=0)
+    opt = optim.AdamW(model.parameters(), lr=2.2e-4, weight_decay=8.6e-4)
+    flat = opt.flat
+    ddp.broadcast_parameters(flat.data)
+    sync = ddp.GradSync(flat.grad, world_size=world)
+    offset_of = {id(p): o for p, o in zip(flat.params, flat.offsets)}
+    enc_names = {n: offset_of[id(p)] for n, p in model.encoder.named_parameters()}
+    head_lo = max(enc_names.values()) + 1   # everything after the encoder's last tensor start
+
+    def hook(names):
+        sync.mark_ready(min(enc_names[n] for n in names))
+    model.encoder.grad_ready_hook = hook
+
+    # synthetic ISIC-shaped data, resident in HBM (bf16 images as the dataset loader would hand them over)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    n_sets = 2
+    labels = [(torch.arange(B, device=dev) + s + rank) % C for s in range(n_sets)]
+    images = [(torch.randn(B, K, 3, S, S, device=dev, generator=g)
+               + 0.25 * labels[s].view(B, 1, 1, 1, 1).float()).to(torch.bfloat16) for s in range(n_sets)]
+    radiom = [torch.randn(B, R, device=dev, generator=g) + 0.25 * labels[s].view(B, 1).float() for s in range(n_sets)]
+
+    timer = KernelTimer(["isic_conv2d_igemm_bf16"])
+    timer.install()
+
+    def step(i):
+        s = i % n_sets
+        opt.zero_grad()
+        sync.reset()
+        out = model(images[s], radiom[s])
+        loss = model.loss(out, labels[s])
+        loss.backward()
+        sync.finish()
+        opt.step(grad_scale=1.0 / world)
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.active = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.active = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.detach())
+
+    if rank == 0:
+        n_launch, conv_ms, conv_fl = timer.summary()
+        achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        line = {
+            "metric": "bags/sec (train step) @ 64x224x224 patches/bag",
+            "value": world * B * args.steps / elapsed,
+            "unit": "bags/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": WORKLOAD, "bags_per_step_per_gpu": B, "global_bags_per_step": B * world,
+                       "patches_per_bag": K, "patch": f"3x{S}x{S}", "radiomics_dim": R,
+                       "parallelism": f"dp{world}", "final_loss": final_loss},
+            "roofline": {
+                "bound": "mfma", "kernel": "conv_igemm_kernel (isic_conv2d_igemm_bf16: forward + data-gradient)",
+                "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                "launches": n_launch, "avg_launch_ms": conv_ms / max(n_launch, 1),
+                "algorithmic_gflop_per_launch": conv_fl / max(n_launch, 1) / 1e9,
+                "share_of_step_time": conv_ms * 1e-3 / elapsed,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(model, K, S, R, C, args.cpu_budget_s)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(model, K, S, R, C, budget_s):
+    """oracle/ per-bag loop on the host cores (kind "port": the build's CPU restatement of the
+    reference loop; the reference itself cannot travel to the GPU box)."""
+    from oracle import model as omodel
+    p = {k: v.detach().float().cpu().contiguous() for k, v in model.state_dict().items()
+         if v.dtype.is_floating_point and "running_" not in k}
+    threads = torch.get_num_threads()
+    g = torch.Generator().manual_seed(7)
+
+    def make_bag(i):
+        y = i % C
+        return (torch.randn(K, 3, S, S, generator=g) + 0.25 * y, torch.randn(1, R, generator=g) + 0.25 * y, y)
+
+    bps, done = omodel.time_per_bag_train_loop(p, make_bag, n_bags=64, warmup=1, budget_s=budget_s)
+    return {"value": bps, "unit": "bags/s", "cores": threads, "kind": "port",
+            "sample": f"{done} per-bag train steps (1 bag of {K}x3x{S}x{S} per optimizer step, fp32, "
+                      f"torch CPU, {threads} threads) after 1 warm-up step",
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()
