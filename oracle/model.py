@@ -24,10 +24,22 @@ def sub(p, prefix):
     return {k[n:]: v for k, v in p.items() if k.startswith(prefix + ".")}
 
 
-def milnet_forward(p, image, radiomics, offsets, emulate_bf16=False, layers=resnet.LAYERS, fusion_strategy="concat"):
-    """image[T,3,H,W], radiomics[B,R], offsets[B+1] -> dict like model.MultiModalMILNet (eval-mode dropout)."""
+def milnet_forward(p, image, radiomics, offsets, emulate_bf16=False, layers=resnet.LAYERS, fusion_strategy="concat",
+                   drop=None, mil_dropout=0.0):
+    """image[T,3,H,W], radiomics[B,R], offsets[B+1] -> dict like model.MultiModalMILNet.
+
+    BatchNorm always uses batch statistics (train mode).  ``drop=None``: no dropout;
+    ``drop=dict(seed, step)``: the product's counter-based train-mode dropout -- sites
+    image_proj (p .3/.2, streams step*1024 + 0/1), radiomics_mlp (.4/.3, +2/3), fusion_mlp (.4, +8)
+    under ``seed``; the MIL head's own site (p = mil_dropout, stream step*1024) under ``seed + 1``."""
     feats = resnet.resnet18_features(sub(p, "encoder"), image, emulate_bf16=emulate_bf16, layers=layers)
-    out = mil.teacher_forward_batched(sub(p, "mil"), feats, offsets)
+    mdrop = None
+    fdrop = None
+    if drop is not None:
+        fdrop = {"seed": drop["seed"], "stream_base": drop["step"] * 1024}
+        if mil_dropout > 0:
+            mdrop = {"p": mil_dropout, "seed": drop["seed"] + 1, "stream": drop["step"] * 1024}
+    out = mil.teacher_forward_batched(sub(p, "mil"), feats, offsets, drop=mdrop)
     H = p["mil.feature_extractor.0.weight"].shape[0]
     pooled = []
     for b in range(len(offsets) - 1):
@@ -35,13 +47,13 @@ def milnet_forward(p, image, radiomics, offsets, emulate_bf16=False, layers=resn
         pooled.append((out["attention"][lo:hi, None] * out["hidden"][lo:hi]).sum(dim=0) if hi > lo
                       else torch.zeros(H))
     z = torch.stack(pooled)
-    img = fusion.mlp_ln_relu(p, "image_proj", z)
-    rad = fusion.mlp_ln_relu(p, "radiomics_mlp", radiomics)
+    img = fusion.mlp_ln_relu(p, "image_proj", z, fdrop, (0.3, 0.2), 0)
+    rad = fusion.mlp_ln_relu(p, "radiomics_mlp", radiomics, fdrop, (0.4, 0.3), 2)
     if fusion_strategy == "concat":
         fused = torch.cat([img, rad], dim=1)
     else:
         fused, _ = fusion.attention_fusion(p, [img, rad])
-    out["logits"] = fusion.fusion_mlp(p, fused)
+    out["logits"] = fusion.fusion_mlp(p, fused, fdrop, 8)
     out["features"] = feats
     return out
 

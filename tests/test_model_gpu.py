@@ -45,6 +45,7 @@ def test_milnet_forward_and_step_vs_oracle():
     net = MultiModalMILNet(hidden_dim=32, att_dim=16, dropout=0.0, radiomics_dim=R, num_classes=C,
                            encoder_layers=layers).to(DEV)
     net.train()
+    net.set_dropout_state(seed=99, step=0)
     g = torch.Generator().manual_seed(5)
     lens = [5, 3, 7, 5, 6, 4]
     offs = np.concatenate([[0], np.cumsum(lens)])
@@ -54,7 +55,7 @@ def test_milnet_forward_and_step_vs_oracle():
     p = {k: v.detach().float().cpu().contiguous() for k, v in net.state_dict().items()
          if v.dtype.is_floating_point and "running_" not in k}
     q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
-    ref = omodel.milnet_forward(q, img, rad, offs, emulate_bf16=True, layers=layers)
+    ref = omodel.milnet_forward(q, img, rad, offs, emulate_bf16=True, layers=layers, drop={"seed": 99, "step": 0})
     lref = omodel.milnet_loss(ref, y)
     lref.backward()
     out = net(img.to(DEV), rad.to(DEV), offsets=offs)
@@ -66,8 +67,8 @@ def test_milnet_forward_and_step_vs_oracle():
         assert err < 0.05 * float(r.abs().max()) + 1e-3, (k, err)
     assert abs(float(loss.detach()) - float(lref)) < 0.03
     for k, prm in net.named_parameters():
-        if k.startswith("encoder"):
-            continue
+        if k.startswith("encoder") or k == "mil.attention.2.bias":
+            continue   # encoder: tests/test_encoder_gpu.py; attention.2.bias: analytically zero gradient (softmax shift invariance)
         gr = q[k].grad
         rel = float((prm.grad.cpu() - gr).norm() / (gr.norm() + 1e-9))
         assert rel < 0.10, (k, rel)
