@@ -136,6 +136,38 @@ int isic_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
                    float eps, float decay_factor, float l2, float bias_correction2_sqrt, float grad_scale,
                    uint16_t* p_bf16, void* stream);
 
+/* ------------------------------------------------------------------ patch-graph adjacency + message passing
+ * k-NN graph on node features (03_build_graphs.py:37-54, utils_g_mil.py:596-615):
+ * per graph g (nodes offsets[g]..offsets[g+1]) d = (|xi|^2 + |xj|^2) - 2 xi.xj in
+ * fp32 (exact-fp32 MFMA dot products), clamp >= 0, diagonal = +inf, the k smallest
+ * per row in ascending order (ties: lower index first).  Writes nn_idx[T,k] as
+ * LOCAL node ids (-1 past a graph's N-1 neighbours) and optionally nn_dist[T,k].
+ * The caller forms edge_index = [repeat(i,k); nn_idx] exactly as the reference.
+ * max_nodes >= the largest graph (<= ~2400), workspace_sqnorm: T floats. */
+int isic_knn_graph(const float* x, const int64_t* offsets, int G, int D, int k, int max_nodes, int64_t total_nodes,
+                   int64_t* nn_idx, float* nn_dist, float* workspace_sqnorm, void* stream);
+
+/* CSR-by-destination with GCN symmetric normalisation (PyG GCNConv.gcn_norm as
+ * called at 05_train_gnns.py:82,184-185): existing self loops are dropped, one
+ * self loop (weight 1, or the dropped loop's weight) is added per node,
+ * deg[i] = sum of weights into i, w^ = deg^-1/2[src] * w * deg^-1/2[dst].
+ * src/dst are GLOBAL node ids over the batched graphs (n_nodes total).
+ * Outputs: rowptr[n_nodes+1], col[E+n_nodes] (source ids; edges keep their
+ * edge_index order within a row, self loop last), val[E+n_nodes]; and the
+ * transposed structure (CSR by source) rowptr_t/col_t/val_t for the backward
+ * pass.  workspace: isic_gcn_csr_workspace_bytes(n_nodes, E) bytes. */
+size_t isic_gcn_csr_workspace_bytes(int64_t n_nodes, int64_t E);
+int isic_gcn_csr_build(const int64_t* src, const int64_t* dst, const float* edge_weight, int64_t E, int64_t n_nodes,
+                       int32_t* rowptr, int32_t* col, float* val, int32_t* rowptr_t, int32_t* col_t, float* val_t,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* out[i,:] = alpha * sum_{e in row i} val[e] * x[col[e],:] (+ bias) (+ addend_scale*addend[i,:])
+ * -- the neighbour gather / segmented sum of GCNConv.propagate
+ * (05_train_gnns.py:184-185); GCN2Conv's (1-alpha) A^ x + alpha x_0 with addend.
+ * With (rowptr_t, col_t, val_t) it is the backward d_x = A^T d_out. */
+int isic_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, const float* bias,
+                      float* out, int64_t n_rows, int F, float alpha, const float* addend, float addend_scale,
+                      void* stream);
+
 /* ------------------------------------------------------------------ patch encoder (bf16 MFMA, NHWC)
  * The reference's encoder is an un-vendored ConvMAE run through torch
  * (save_latent.py:42-60); BASELINE.json configs[1] names ResNet-18 (layer table:

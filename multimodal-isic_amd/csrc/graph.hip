@@ -1,0 +1,336 @@
+// Patch-graph kernels (gfx950): k-NN adjacency build, CSR-by-destination with GCN symmetric
+// normalisation, and the neighbour gather / segmented sum (CSR SpMM) of message passing.
+//
+//   isic_knn_graph        03_build_graphs.py:37-54 / utils_g_mil.py:596-615 (distance GEMM + top-k)
+//   isic_gcn_csr_build    PyG GCNConv.gcn_norm as called at 05_train_gnns.py:82,184-185
+//   isic_spmm_csr_f32     GCNConv.propagate: out[dst] += w^ * x[src]   (05_train_gnns.py:184-185)
+//
+// The gather/scatter is re-expressed as a destination-major CSR so that the "scatter" becomes a
+// segmented sum owned by one wave per destination row: no atomics, deterministic order (edges keep
+// their edge_index order inside a row), every neighbour row is read with one coalesced wave-wide
+// load, every output row written once.  The backward pass is the same kernel on the transposed CSR.
+#include "common.h"
+
+namespace {
+
+// ================================================================= k-NN
+// block = (graph, 16 query rows).  distances of the 16 queries to all N nodes of the graph via
+// exact-fp32 MFMA (16x16x4) in chunks of 64 candidates (one 16x16 tile per wave), kept in LDS;
+// then k rounds of wave-wide arg-min per query row (ties -> lower index).
+__global__ void row_sqnorm_kernel(const float* __restrict__ x, int64_t T, int D, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= T) return;
+  float s = 0.f;
+  for (int j = lane; j < D; j += 64) { const float v = x[row * D + j]; s += v * v; }
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s;
+}
+
+__global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ x, const float* __restrict__ sqn,
+                                                   const int64_t* __restrict__ offsets, int D, int k, int max_nodes,
+                                                   int64_t* __restrict__ nn_idx, float* __restrict__ nn_dist) {
+  extern __shared__ __attribute__((aligned(16))) float dist[];   // [16][npad]
+  const int g = blockIdx.y, rt = blockIdx.x;
+  const int64_t lo = offsets[g];
+  const int N = (int)(offsets[g + 1] - lo);
+  const int r0 = rt * 16;
+  if (r0 >= N) return;
+  const int npad = ((max_nodes + 63) / 64) * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const bool vec = (D % 4) == 0;
+  const int qrow = r0 + fr;                                   // this lane's query row (A operand)
+  const float* qp = x + (lo + (qrow < N ? qrow : N - 1)) * D;
+  for (int c0 = 0; c0 < N; c0 += 64) {
+    const int ccol = c0 + wave * 16 + fr;                     // this lane's candidate (B operand)
+    const float* cp = x + (lo + (ccol < N ? ccol : N - 1)) * D;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int d0 = 0; d0 < D; d0 += 16) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+      const int d = d0 + 4 * fg;
+      if (vec && d + 3 < D) {
+        a = *reinterpret_cast<const float4*>(qp + d);
+        b = *reinterpret_cast<const float4*>(cp + d);
+      } else {
+        if (d < D) { a.x = qp[d]; b.x = cp[d]; }
+        if (d + 1 < D) { a.y = qp[d + 1]; b.y = cp[d + 1]; }
+        if (d + 2 < D) { a.z = qp[d + 2]; b.z = cp[d + 2]; }
+        if (d + 3 < D) { a.w = qp[d + 3]; b.w = cp[d + 3]; }
+      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    // C map: row(query) = fg*4 + r, col(candidate) = fr
+    const int col = c0 + wave * 16 + fr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = r0 + fg * 4 + r;
+      float dv = INFINITY;
+      if (q < N && col < N && q != col) {
+        dv = (sqn[lo + q] + sqn[lo + col]) - 2.0f * acc[r];   // 03_build_graphs.py:47
+        dv = fmaxf(dv, 0.f);                                  // :48 clamp(min=0)
+      }
+      dist[(fg * 4 + r) * npad + col] = dv;
+    }
+  }
+  __syncthreads();
+  // top-k: wave w owns query rows w*4 .. w*4+3
+  for (int rr = 0; rr < 4; ++rr) {
+    const int ql = wave * 4 + rr, q = r0 + ql;
+    if (q >= N) continue;
+    float* drow = dist + ql * npad;
+    for (int j = 0; j < k; ++j) {
+      float best = INFINITY;
+      int bi = 0x7FFFFFFF;
+      for (int c = lane; c < N; c += 64) {
+        const float v = drow[c];
+        if (v < best) { best = v; bi = c; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      }
+      const bool found = best < INFINITY;
+      if (lane == 0) {
+        nn_idx[(lo + q) * k + j] = found ? (int64_t)bi : (int64_t)-1;
+        if (nn_dist) nn_dist[(lo + q) * k + j] = found ? best : INFINITY;
+        if (found) drow[bi] = INFINITY;
+      }
+      __builtin_amdgcn_wave_barrier();
+      __threadfence_block();
+    }
+  }
+}
+
+// ================================================================= GCN CSR
+__global__ void csr_init_kernel(int* __restrict__ cnt, float* __restrict__ loopw, int64_t n) {
+  // cnt holds 4 int arrays of n: cnt_in, cnt_out, fill_in, fill_out
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < 4 * n; i += stride) cnt[i] = 0;
+  i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += stride) loopw[i] = 1.0f;
+}
+
+__global__ void csr_count_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                                 const float* __restrict__ w, int64_t E, int64_t n, int* __restrict__ cnt_in,
+                                 int* __restrict__ cnt_out, float* __restrict__ loopw) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; e < E; e += stride) {
+    const int64_t s = src[e], d = dst[e];
+    if (s == d) { loopw[s] = w ? w[e] : 1.0f; }
+    else { atomicAdd(&cnt_in[d], 1); atomicAdd(&cnt_out[s], 1); }
+  }
+}
+
+// single-block exclusive scan of (cnt[i] + 1) for both directions
+__global__ __launch_bounds__(1024) void csr_scan_kernel(const int* __restrict__ cnt_in, const int* __restrict__ cnt_out,
+                                                         int64_t n, int* __restrict__ rowptr, int* __restrict__ rowptr_t) {
+  __shared__ int part[2][1024];
+  const int tid = threadIdx.x;
+  const int64_t per = (n + 1023) / 1024;
+  const int64_t b = tid * per, e = (b + per < n) ? b + per : n;
+  int s0 = 0, s1 = 0;
+  for (int64_t i = b; i < e; ++i) { s0 += cnt_in[i] + 1; s1 += cnt_out[i] + 1; }
+  part[0][tid] = s0; part[1][tid] = s1;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v0 = 0, v1 = 0;
+    if (tid >= off) { v0 = part[0][tid - off]; v1 = part[1][tid - off]; }
+    __syncthreads();
+    part[0][tid] += v0; part[1][tid] += v1;
+    __syncthreads();
+  }
+  int r0 = part[0][tid] - s0, r1 = part[1][tid] - s1;   // exclusive prefix of this thread's chunk
+  for (int64_t i = b; i < e; ++i) {
+    rowptr[i] = r0; rowptr_t[i] = r1;
+    r0 += cnt_in[i] + 1; r1 += cnt_out[i] + 1;
+  }
+  if (tid == 1023) { rowptr[n] = part[0][1023]; rowptr_t[n] = part[1][1023]; }
+}
+
+__global__ void csr_fill_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                                const float* __restrict__ w, int64_t E, const int* __restrict__ rowptr,
+                                const int* __restrict__ rowptr_t, int* __restrict__ fill_in, int* __restrict__ fill_out,
+                                int* __restrict__ col, float* __restrict__ val, int* __restrict__ eid,
+                                int* __restrict__ col_t, float* __restrict__ val_t, int* __restrict__ eid_t) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; e < E; e += stride) {
+    const int64_t s = src[e], d = dst[e];
+    if (s == d) continue;
+    const float wv = w ? w[e] : 1.0f;
+    const int p = rowptr[d] + atomicAdd(&fill_in[d], 1);
+    col[p] = (int)s; val[p] = wv; eid[p] = (int)e;
+    const int pt = rowptr_t[s] + atomicAdd(&fill_out[s], 1);
+    col_t[pt] = (int)d; val_t[pt] = wv; eid_t[pt] = (int)e;
+  }
+}
+
+// per row: order entries by original edge id (deterministic), append the self loop, degree
+__device__ void sort_row(int* col, float* val, int* eid, int b, int e) {
+  for (int i = b + 1; i < e; ++i) {
+    const int ke = eid[i], kc = col[i];
+    const float kv = val[i];
+    int j = i - 1;
+    while (j >= b && eid[j] > ke) { eid[j + 1] = eid[j]; col[j + 1] = col[j]; val[j + 1] = val[j]; --j; }
+    eid[j + 1] = ke; col[j + 1] = kc; val[j + 1] = kv;
+  }
+}
+__global__ void csr_sort_kernel(const int* __restrict__ rowptr, const int* __restrict__ rowptr_t, int64_t n,
+                                const float* __restrict__ loopw, int* __restrict__ col, float* __restrict__ val,
+                                int* __restrict__ eid, int* __restrict__ col_t, float* __restrict__ val_t,
+                                int* __restrict__ eid_t, float* __restrict__ dis) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  {
+    const int b = rowptr[i], e = rowptr[i + 1] - 1;   // last slot = self loop
+    sort_row(col, val, eid, b, e);
+    col[e] = (int)i; val[e] = loopw[i];
+    float deg = 0.f;
+    for (int p = b; p <= e; ++p) deg += val[p];        // deg[i] = sum of weights INTO i (+ loop)
+    dis[i] = deg > 0.f ? 1.0f / sqrtf(deg) : 0.f;      // deg^-1/2, inf -> 0
+  }
+  {
+    const int b = rowptr_t[i], e = rowptr_t[i + 1] - 1;
+    sort_row(col_t, val_t, eid_t, b, e);
+    col_t[e] = (int)i; val_t[e] = loopw[i];
+  }
+}
+__global__ void csr_norm_kernel(const int* __restrict__ rowptr, const int* __restrict__ rowptr_t, int64_t n,
+                                const float* __restrict__ dis, const int* __restrict__ col, float* __restrict__ val,
+                                const int* __restrict__ col_t, float* __restrict__ val_t) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // w^ = dis[src] * w * dis[dst]  (PyG order of operations)
+  for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) val[p] = (dis[col[p]] * val[p]) * dis[i];        // row = dst
+  for (int p = rowptr_t[i]; p < rowptr_t[i + 1]; ++p) val_t[p] = (dis[i] * val_t[p]) * dis[col_t[p]];  // row = src
+}
+
+// ================================================================= SpMM
+// one wave per output row; lanes stride the F features (coalesced 256-B..1-KB row reads)
+template <int VEC>
+__global__ __launch_bounds__(256) void spmm_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                    const float* __restrict__ val, const float* __restrict__ x,
+                                                    const float* __restrict__ bias, float* __restrict__ out,
+                                                    int64_t n_rows, int F, float alpha, const float* __restrict__ addend,
+                                                    float addend_scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const int b = rowptr[row], e = rowptr[row + 1];
+  for (int f0 = lane * VEC; f0 < F; f0 += 64 * VEC) {
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    for (int p = b; p < e; ++p) {
+      const float w = val[p];
+      const float* xr = x + (int64_t)col[p] * F + f0;
+      if (VEC == 4) {
+        const float4 xv = *reinterpret_cast<const float4*>(xr);
+        acc[0] += w * xv.x; acc[1 % VEC] += w * xv.y; acc[2 % VEC] += w * xv.z; acc[3 % VEC] += w * xv.w;
+      } else if (VEC == 2) {
+        const float2 xv = *reinterpret_cast<const float2*>(xr);
+        acc[0] += w * xv.x; acc[1 % VEC] += w * xv.y;
+      } else {
+        acc[0] += w * xr[0];
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      float o = alpha * acc[v];
+      if (bias) o += bias[f0 + v];
+      if (addend) o += addend_scale * addend[row * F + f0 + v];
+      out[row * F + f0 + v] = o;
+    }
+  }
+}
+
+inline int grid_for(int64_t n, int block, int cap = 4096) {
+  int64_t g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int isic_knn_graph(const float* x, const int64_t* offsets, int G, int D, int k, int max_nodes, int64_t total_nodes,
+                   int64_t* nn_idx, float* nn_dist, float* workspace_sqnorm, void* stream) {
+  ISIC_CHECK_ARG(G >= 0 && D > 0 && k > 0 && max_nodes >= 0 && total_nodes >= 0);
+  if (G == 0 || total_nodes == 0 || max_nodes == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(x && offsets && nn_idx && workspace_sqnorm);
+  const int npad = ((max_nodes + 63) / 64) * 64;
+  const size_t lds = (size_t)16 * npad * sizeof(float);
+  if (lds > 150 * 1024) return ISIC_ERR_UNSUPPORTED;   // > ~2400 nodes per graph
+  if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(knn_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return ISIC_ERR_LAUNCH;
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)((total_nodes + 3) / 4)), dim3(256), 0, as_stream(stream), x,
+                     total_nodes, D, workspace_sqnorm);
+  dim3 grid(ceil_div(max_nodes, 16), G);
+  ISIC_CHECK_ARG(grid.y <= 65535u);
+  hipLaunchKernelGGL(knn_kernel, grid, dim3(256), lds, as_stream(stream), x, workspace_sqnorm, offsets, D, k, max_nodes,
+                     nn_idx, nn_dist);
+  return isic_launch_status();
+}
+
+size_t isic_gcn_csr_workspace_bytes(int64_t n_nodes, int64_t E) {
+  // cnt_in, cnt_out, fill_in, fill_out (int) | loopw, dis (float) | eid, eid_t (int, E+n each)
+  return (size_t)(6 * n_nodes + 2 * (E + n_nodes) + 64) * 4;
+}
+
+int isic_gcn_csr_build(const int64_t* src, const int64_t* dst, const float* edge_weight, int64_t E, int64_t n_nodes,
+                       int32_t* rowptr, int32_t* col, float* val, int32_t* rowptr_t, int32_t* col_t, float* val_t,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+  ISIC_CHECK_ARG(E >= 0 && n_nodes > 0 && rowptr && col && val && rowptr_t && col_t && val_t && workspace);
+  ISIC_CHECK_ARG(E == 0 || (src && dst));
+  if (E + n_nodes > 0x7FFFFFF0LL) return ISIC_ERR_UNSUPPORTED;
+  if (workspace_bytes < isic_gcn_csr_workspace_bytes(n_nodes, E)) return ISIC_ERR_WORKSPACE;
+  int* cnt = reinterpret_cast<int*>(workspace);
+  int *cnt_in = cnt, *cnt_out = cnt + n_nodes, *fill_in = cnt + 2 * n_nodes, *fill_out = cnt + 3 * n_nodes;
+  float* loopw = reinterpret_cast<float*>(cnt + 4 * n_nodes);
+  float* dis = loopw + n_nodes;
+  int* eid = reinterpret_cast<int*>(dis + n_nodes);
+  int* eid_t = eid + (E + n_nodes);
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(csr_init_kernel, dim3(grid_for(4 * n_nodes, 256)), dim3(256), 0, s, cnt, loopw, n_nodes);
+  if (E > 0)
+    hipLaunchKernelGGL(csr_count_kernel, dim3(grid_for(E, 256)), dim3(256), 0, s, src, dst, edge_weight, E, n_nodes,
+                       cnt_in, cnt_out, loopw);
+  hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, s, cnt_in, cnt_out, n_nodes, rowptr, rowptr_t);
+  if (E > 0)
+    hipLaunchKernelGGL(csr_fill_kernel, dim3(grid_for(E, 256)), dim3(256), 0, s, src, dst, edge_weight, E, rowptr,
+                       rowptr_t, fill_in, fill_out, col, val, eid, col_t, val_t, eid_t);
+  const int g = (int)((n_nodes + 255) / 256);
+  hipLaunchKernelGGL(csr_sort_kernel, dim3(g), dim3(256), 0, s, rowptr, rowptr_t, n_nodes, loopw, col, val, eid, col_t,
+                     val_t, eid_t, dis);
+  hipLaunchKernelGGL(csr_norm_kernel, dim3(g), dim3(256), 0, s, rowptr, rowptr_t, n_nodes, dis, col, val, col_t, val_t);
+  return isic_launch_status();
+}
+
+int isic_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, const float* bias,
+                      float* out, int64_t n_rows, int F, float alpha, const float* addend, float addend_scale,
+                      void* stream) {
+  ISIC_CHECK_ARG(n_rows >= 0 && F > 0);
+  if (n_rows == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(rowptr && col && val && x && out);
+  const dim3 grid((unsigned)((n_rows + 3) / 4));
+  hipStream_t s = as_stream(stream);
+  const bool al16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  if (F % 4 == 0 && al16 && F >= 256)
+    hipLaunchKernelGGL(spmm_kernel<4>, grid, dim3(256), 0, s, rowptr, col, val, x, bias, out, n_rows, F, alpha, addend, addend_scale);
+  else if (F % 2 == 0 && al16 && F >= 128)
+    hipLaunchKernelGGL(spmm_kernel<2>, grid, dim3(256), 0, s, rowptr, col, val, x, bias, out, n_rows, F, alpha, addend, addend_scale);
+  else
+    hipLaunchKernelGGL(spmm_kernel<1>, grid, dim3(256), 0, s, rowptr, col, val, x, bias, out, n_rows, F, alpha, addend, addend_scale);
+  return isic_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,167 @@
+"""``GraphMIL``: patch-graph GNN + multi-head attention pooling on the MI355X.
+
+Same constructor, ``state_dict`` key names and ``forward(x, edge_index, edge_weight)
+-> (probs, attention_weights)`` as the class the reference defines inside
+`05_train_gnns.py:51-219`; message passing runs as a destination-major CSR SpMM
+(``isic_spmm_csr_f32``), dense layers on exact-fp32 MFMA, LayerNorm/ReLU/dropout/
+residual fused in one kernel, the 4-head attention pool in one launch per batch.
+
+Graph models: ``mlp`` (pure dense, pinned by the reference), ``gcn`` and ``gcnii``
+(PyG ``GCNConv`` / ``GCN2Conv`` semantics restated -- ``torch_geometric`` is absent
+and unpinned in the reference, see oracle/gnn.py).  The edge-softmax / mean /
+sum-aggregation variants (``gat``, ``gatv2``, ``graphsage``, ``gin``, ``transformer``,
+``fagcn``) are not built yet and raise ``NotImplementedError``.
+
+Beyond the reference: ``forward`` also takes a batch of graphs (``offsets`` + global node ids,
+or a prebuilt ``GraphBatch``) and returns ``probs[G, C]``.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from isic_hip import ops
+from isic_hip.bags import BagOffsets, as_offsets
+from isic_hip.graph import GraphBatch, spmm
+from utils_g_mil import _DropoutClock
+
+GNN_TYPES = ("mlp", "gcn", "gat", "gatv2", "gin", "graphsage", "transformer", "fagcn", "gcnii")
+_BUILT = ("mlp", "gcn", "gcnii")
+
+
+class _GCNConvParams(nn.Module):
+    """Parameter holder with PyG ``GCNConv`` names: ``bias`` [F], ``lin.weight`` [F, in] (Glorot / zeros)."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(out_dim))
+        self.lin = nn.Linear(in_dim, out_dim, bias=False)
+        nn.init.xavier_uniform_(self.lin.weight)
+
+
+class _GCN2ConvParams(nn.Module):
+    """PyG ``GCN2Conv`` (shared weights): ``weight1`` [F, F], Glorot."""
+
+    def __init__(self, channels, alpha, theta, layer):
+        super().__init__()
+        self.weight1 = nn.Parameter(torch.empty(channels, channels))
+        nn.init.xavier_uniform_(self.weight1)
+        self.alpha = float(alpha)
+        self.beta = math.log(theta / layer + 1.0)
+
+
+class GraphMIL(nn.Module):
+    def __init__(self, input_dim=768, gnn_type='gat', gnn_hidden=256, gnn_layers=2, gnn_dropout=0.1, gnn_heads=4,
+                 gnn_concat=True, gcnii_alpha=0.1, gcnii_theta=0.5, att_dim=128, att_heads=4, pool_dropout=0.2,
+                 classifier_dim=128, classifier_light=False, num_classes=7, use_residual=True, use_layer_norm=True):
+        super().__init__()
+        self.gnn_type = gnn_type.lower()
+        if self.gnn_type not in GNN_TYPES:
+            raise ValueError(f"Unsupported gnn_type: {self.gnn_type}")           # 05:113-114
+        if self.gnn_type not in _BUILT:
+            raise NotImplementedError(f"gnn_type '{self.gnn_type}' is not built on the HIP path yet "
+                                      f"(available: {', '.join(_BUILT)})")
+        self.use_residual, self.use_layer_norm = use_residual, use_layer_norm
+        self.classifier_light, self.gnn_heads, self.gnn_concat = classifier_light, gnn_heads, gnn_concat
+        if (use_residual or self.gnn_type in {"fagcn", "gcnii"}) and input_dim != gnn_hidden:   # 05:65-68
+            self.input_proj = nn.Linear(input_dim, gnn_hidden)
+        else:
+            self.input_proj = None
+        self.gnn_layers = nn.ModuleList()
+        self.layer_norms = nn.ModuleList() if use_layer_norm else None
+        in_dim = input_dim if self.input_proj is None else gnn_hidden
+        for i in range(gnn_layers):
+            out_dim = gnn_hidden
+            if self.gnn_type == 'gcn':
+                layer = _GCNConvParams(in_dim, out_dim)
+            elif self.gnn_type == 'gcnii':
+                if in_dim != out_dim:
+                    raise ValueError("GCNII requires a constant hidden dimension across layers")
+                layer = _GCN2ConvParams(out_dim, gcnii_alpha, gcnii_theta, i + 1)
+            else:
+                layer = nn.Sequential(nn.Linear(in_dim, out_dim))
+            self.gnn_layers.append(layer)
+            if use_layer_norm:
+                self.layer_norms.append(nn.LayerNorm(out_dim))
+            in_dim = out_dim
+        self.gnn_dropout = nn.Dropout(gnn_dropout)
+        self.final_gnn_dim = in_dim
+        self.att_heads = att_heads
+        self.attention_layers = nn.ModuleList([
+            nn.Sequential(nn.Linear(in_dim, att_dim), nn.Tanh(), nn.Linear(att_dim, 1)) for _ in range(att_heads)])
+        if classifier_light:
+            self.classifier = nn.Sequential(nn.Linear(in_dim, classifier_dim), nn.ReLU(), nn.Dropout(pool_dropout),
+                                            nn.Linear(classifier_dim, num_classes))
+        else:
+            h2 = classifier_dim // 2
+            self.classifier = nn.Sequential(
+                nn.Linear(in_dim, classifier_dim), nn.LayerNorm(classifier_dim), nn.ReLU(), nn.Dropout(pool_dropout),
+                nn.Linear(classifier_dim, h2), nn.LayerNorm(h2), nn.ReLU(), nn.Dropout(pool_dropout / 2),
+                nn.Linear(h2, num_classes))
+        self.dropout_clock = _DropoutClock()
+        self.last_node_embeddings = None
+
+    def set_dropout_state(self, seed, step=0):
+        self.dropout_clock.seed, self.dropout_clock.step = int(seed), int(step)
+
+    def _graph(self, edge_index, edge_weight, n_nodes, graph):
+        if self.gnn_type == 'mlp':
+            return None
+        if graph is not None:
+            return graph
+        if edge_index is None:
+            raise ValueError(f"gnn_type '{self.gnn_type}' needs edge_index")
+        return GraphBatch(edge_index, n_nodes, edge_weight)
+
+    def forward(self, x, edge_index=None, edge_weight=None, offsets=None, graph=None):
+        """x[N, D] (+ edge_index[2, E]) -> (probs[C], attention_weights[N, heads]) as the reference
+        (`05_train_gnns.py:156-219`); with ``offsets`` (graph boundaries, global node ids) the batch
+        form returns probs[G, C]."""
+        single = offsets is None
+        offs = BagOffsets.single(x.shape[0], x.device) if single else as_offsets(offsets, x.device)
+        clk, tr = self.dropout_clock, self.training
+        g = self._graph(edge_index, edge_weight, x.shape[0], graph)
+        x_in = ops.linear(x, self.input_proj.weight, self.input_proj.bias) if self.input_proj is not None else x
+        h, x0 = x_in, x_in
+        p_drop = self.gnn_dropout.p
+        for i, layer in enumerate(self.gnn_layers):
+            h_prev = h
+            if self.gnn_type == 'mlp':
+                h = ops.linear(h, layer[0].weight, layer[0].bias)
+            elif self.gnn_type == 'gcn':
+                h = spmm(ops.linear(h, layer.lin.weight, None), g, bias=layer.bias)
+            else:  # gcnii: (1-beta) p + beta p W1 with p = (1-alpha) A^ h + alpha x0  ==  p @ ((1-beta) I + beta W1)
+                p = spmm(h, g, alpha=1.0 - layer.alpha, addend=x0, addend_scale=layer.alpha)
+                eye = torch.eye(layer.weight1.shape[0], device=p.device, dtype=torch.float32)
+                w_eff = (1.0 - layer.beta) * eye + layer.beta * layer.weight1
+                h = ops.linear(p, w_eff.t(), None)
+            res = h_prev if (self.use_residual and h_prev.shape == h.shape) else None
+            if self.use_layer_norm:
+                ln = self.layer_norms[i]
+                h = ops.layer_norm(h, ln.weight, ln.bias, ln.eps, relu=True, drop=clk.spec(p_drop, i, tr), residual=res)
+            else:
+                h = ops.relu_dropout(h, clk.spec(p_drop, i, tr))
+                if res is not None:
+                    h = h + res
+        self.last_node_embeddings = h.detach()
+        W2 = torch.cat([a[0].weight for a in self.attention_layers], dim=0)
+        b2 = torch.cat([a[0].bias for a in self.attention_layers], dim=0)
+        w3 = torch.cat([a[2].weight for a in self.attention_layers], dim=0)
+        b3 = torch.cat([a[2].bias for a in self.attention_layers], dim=0)
+        z, att = ops.attn_pool(h, W2, b2, w3, b3, offs.device, offs.max_bag, heads=self.att_heads)
+        c = self.classifier
+        if self.classifier_light:
+            u = ops.linear(z, c[0].weight, c[0].bias, ops.ACT_RELU, clk.spec(c[2].p, 64, tr))
+            logits = ops.linear(u, c[3].weight, c[3].bias)
+        else:
+            u = ops.layer_norm(ops.linear(z, c[0].weight, c[0].bias), c[1].weight, c[1].bias, c[1].eps, relu=True,
+                               drop=clk.spec(c[3].p, 64, tr))
+            u = ops.layer_norm(ops.linear(u, c[4].weight, c[4].bias), c[5].weight, c[5].bias, c[5].eps, relu=True,
+                               drop=clk.spec(c[7].p, 65, tr))
+            logits = ops.linear(u, c[8].weight, c[8].bias)
+        probs = ops.softmax_rows(logits)
+        if tr:
+            clk.step += 1
+        return (probs[0], att) if single else (probs, att)

@@ -1,0 +1,87 @@
+"""Patch-graph structures and message-passing ops over libisic_hip (k-NN build,
+destination-major CSR with GCN normalisation, CSR SpMM with autograd)."""
+from __future__ import annotations
+
+import torch
+
+from .bags import BagOffsets
+from .lib import IsicHipError, call
+from .ops import _chk, _f32c, colsum
+
+
+def knn_indices(x, offsets: BagOffsets, k, return_dist=False):
+    """k nearest neighbours of every node inside its own graph -> LOCAL ids [T, k] (int64),
+    ascending by distance (`03_build_graphs.py:46-50`)."""
+    _chk(x)
+    x = _f32c(x)
+    T, D = x.shape
+    if T != offsets.total:
+        raise ValueError(f"x has {T} rows but offsets cover {offsets.total}")
+    idx = torch.empty((T, k), device=x.device, dtype=torch.int64)
+    dist = torch.empty((T, k), device=x.device, dtype=torch.float32) if return_dist else None
+    ws = torch.empty((T,), device=x.device, dtype=torch.float32)
+    call("isic_knn_graph", x, offsets.device, offsets.num_bags, D, int(k), offsets.max_bag, T, idx, dist, ws)
+    return (idx, dist) if return_dist else idx
+
+
+class GraphBatch:
+    """Destination-major CSR (+ its transpose) of a batch of graphs with GCN symmetric
+    normalisation and self loops (PyG ``gcn_norm`` semantics, `05_train_gnns.py:82`)."""
+
+    def __init__(self, edge_index, n_nodes, edge_weight=None):
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise ValueError("edge_index must be [2, E]")
+        if not edge_index.is_cuda:
+            raise IsicHipError("GraphBatch needs device tensors (no CPU fallback)")
+        ei = edge_index.to(torch.int64).contiguous()
+        E, n = int(ei.shape[1]), int(n_nodes)
+        dev = ei.device
+        ew = _f32c(edge_weight) if edge_weight is not None else None
+        self.n_nodes, self.num_edges = n, E
+        self.rowptr = torch.empty(n + 1, device=dev, dtype=torch.int32)
+        self.col = torch.empty(E + n, device=dev, dtype=torch.int32)
+        self.val = torch.empty(E + n, device=dev, dtype=torch.float32)
+        self.rowptr_t = torch.empty(n + 1, device=dev, dtype=torch.int32)
+        self.col_t = torch.empty(E + n, device=dev, dtype=torch.int32)
+        self.val_t = torch.empty(E + n, device=dev, dtype=torch.float32)
+        nbytes = (6 * n + 2 * (E + n) + 64) * 4
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        call("isic_gcn_csr_build", ei[0], ei[1], ew, E, n, self.rowptr, self.col, self.val, self.rowptr_t, self.col_t,
+             self.val_t, ws, nbytes)
+
+
+class SpmmFn(torch.autograd.Function):
+    """out = alpha * A^ x (+ bias) (+ addend_scale * addend); backward through the transposed CSR."""
+
+    @staticmethod
+    def forward(ctx, x, graph, bias, alpha, addend, addend_scale):
+        _chk(x, bias, addend)
+        x2 = _f32c(x)
+        n, F = x2.shape
+        if n != graph.n_nodes:
+            raise ValueError(f"x has {n} rows, graph has {graph.n_nodes} nodes")
+        out = torch.empty_like(x2)
+        call("isic_spmm_csr_f32", graph.rowptr, graph.col, graph.val, x2, _f32c(bias) if bias is not None else None, out,
+             n, F, float(alpha), _f32c(addend) if addend is not None else None, float(addend_scale))
+        ctx.graph, ctx.alpha, ctx.addend_scale = graph, float(alpha), float(addend_scale)
+        ctx.has_bias, ctx.has_addend = bias is not None, addend is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = ctx.graph
+        dy = _f32c(dy)
+        dx = db = da = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(dy)
+            call("isic_spmm_csr_f32", g.rowptr_t, g.col_t, g.val_t, dy, None, dx, dy.shape[0], dy.shape[1], ctx.alpha,
+                 None, 0.0)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy)
+        if ctx.has_addend and ctx.needs_input_grad[4]:
+            da = dy * ctx.addend_scale
+        return dx, None, db, None, da, None
+
+
+def spmm(x, graph, bias=None, alpha=1.0, addend=None, addend_scale=0.0):
+    return SpmmFn.apply(x, graph, bias, alpha, addend, addend_scale)

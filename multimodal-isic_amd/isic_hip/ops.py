@@ -125,6 +125,31 @@ def linear(x, weight, bias=None, act=ACT_NONE, drop=None):
     return LinearFn.apply(x, weight, bias, act, drop)
 
 
+class ReluDropoutFn(torch.autograd.Function):
+    """y = dropout(relu(x)) (`05_train_gnns.py:189-190` without LayerNorm)."""
+
+    @staticmethod
+    def forward(ctx, x, drop):
+        _chk(x)
+        drop = drop or NO_DROP
+        y = _f32c(x).clone()
+        call("isic_relu_dropout_fwd_f32", y, y.numel(), drop.threshold, drop.scale, drop.seed, drop.stream)
+        ctx.scale = drop.scale if drop.active else 1.0
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        g = _f32c(dy).clone()
+        call("isic_relu_dropout_bwd_f32", y, g, g.numel(), ctx.scale)
+        return g, None
+
+
+def relu_dropout(x, drop=None):
+    return ReluDropoutFn.apply(x, drop)
+
+
 # --------------------------------------------------------------------------- attention pool
 class AttnPoolFn(torch.autograd.Function):
     """Attention scores + segmented softmax + pooling over ragged bags.

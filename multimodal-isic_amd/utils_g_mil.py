@@ -130,3 +130,67 @@ def set_seed(seed: int = 42):
     torch.manual_seed(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
+
+
+# ----------------------------------------------------------------------------- graph builders / graph-MIL
+_GRID_ADJ_CACHE = {}
+
+
+def build_grid_adj(num_nodes, connect_diagonals=False, device=None):
+    """Reference `utils_g_mil.py:564-589`: dense (A + I) row-normalised by degree; returns
+    ``(adj_norm, adj_mask)``.  Constant integer geometry: built once on the host."""
+    s = int(np.sqrt(num_nodes))
+    if s * s != num_nodes:
+        raise ValueError('num_nodes must be a perfect square to build grid adjacency')
+    from build_graphs import _grid_edge_index
+    e = _grid_edge_index(connect_diagonals, side=s)
+    adj = torch.zeros((num_nodes, num_nodes), dtype=torch.float32)
+    adj[e[0], e[1]] = 1.0
+    adj = adj + torch.eye(num_nodes)
+    adj_norm = adj / adj.sum(dim=1, keepdim=True)
+    if device is not None:
+        adj_norm = adj_norm.to(device)
+    return adj_norm, (adj > 0).float()
+
+
+def build_knn_edge_index(x, k=8, device=None):
+    """Reference `utils_g_mil.py:596-615`: k-NN ``edge_index[2, N*k]`` (HIP distance + top-k)."""
+    from build_graphs import knn_edge_index_batched
+    n = x.size(0)
+    e = knn_edge_index_batched(x, [0, n], [min(int(k), n - 1)])[min(int(k), n - 1)]
+    return e.to(x.device if device is None else device)
+
+
+def build_graph(x, graph_type='grid', k=None, connect_diagonals=False, device=None):
+    """Reference `utils_g_mil.py:618-674`: ``(adj_norm, adj_mask, edge_index, edge_weight)``."""
+    num_nodes = x.size(0)
+    if graph_type == 'grid':
+        key = (num_nodes, bool(connect_diagonals), str(device))
+        if key not in _GRID_ADJ_CACHE:
+            _GRID_ADJ_CACHE[key] = build_grid_adj(num_nodes, connect_diagonals=connect_diagonals, device=device)
+        adj_norm, adj_mask = _GRID_ADJ_CACHE[key]
+        mask = adj_mask.bool()
+        edge_index = mask.nonzero(as_tuple=False).t().to(x.device).long()
+        edge_weight = adj_norm.to(mask.device)[mask].to(x.device)
+        return adj_norm, adj_mask, edge_index, edge_weight
+    if graph_type == 'knn':
+        return None, None, build_knn_edge_index(x, k=8 if k is None else int(k), device=device), None
+    if graph_type == 'random':
+        from build_graphs import _random_edge_index
+        return None, None, _random_edge_index(num_nodes, r=k if k is not None else 4).to(x.device), None
+    raise ValueError(f"Unsupported graph_type='{graph_type}'. Supported types: 'grid', 'knn'.")
+
+
+def __getattr__(name):
+    # ``from utils_g_mil import GraphMIL`` (use_latent.py:21): the older copy of the class takes
+    # (x, adj, adj_mask, edge_index, edge_weight); resolved lazily to avoid a circular import.
+    if name == "GraphMIL":
+        from gnn_models import GraphMIL as _G
+
+        class GraphMIL(_G):
+            def forward(self, x, adj=None, adj_mask=None, edge_index=None, edge_weight=None):
+                return super().forward(x, edge_index=edge_index, edge_weight=edge_weight)
+
+        globals()["GraphMIL"] = GraphMIL
+        return GraphMIL
+    raise AttributeError(name)

