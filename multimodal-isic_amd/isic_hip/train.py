@@ -1,0 +1,279 @@
+"""Host-side train / eval loops of the MIL teacher (`01_train_mil_teacher.py:170-305`)
+and of the patch-graph GNN (`05_train_gnns.py:273-358`) over the HIP path, with the two
+things the reference does not have: several bags / graphs per optimizer step in one
+launch, and bag-sharded data parallelism (one process per GPU, RCCL gradient all-reduce
+through ``ddp.GradSync``).
+
+Step semantics (SURVEY.md §7 "Batch-vs-per-bag"): with ``per_step=1, world=1`` these loops
+ARE the reference loops (one optimizer step per bag / graph); with B bags per step the loss
+is the mean of the per-bag reference losses and the gradient the mean of the per-bag
+gradients.
+"""
+from __future__ import annotations
+
+import copy
+import os
+from collections import Counter
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import ddp, ops, optim
+from .bags import BagOffsets
+from .graph import GraphBatch
+
+
+def dist_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def init_distributed():
+    """One process per GPU under torchrun / torch.distributed.run; no-op otherwise."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return dist_info()
+
+
+def weighted_sample_indices(labels, generator):
+    """`01_train_mil_teacher.py:189-193`: WeightedRandomSampler(1/class_count, n, replacement=True)."""
+    labels = np.asarray(labels)
+    counts = Counter(labels.tolist())
+    w = torch.tensor([1.0 / counts[int(l)] for l in labels], dtype=torch.float64)
+    return torch.multinomial(w, len(labels), replacement=True, generator=generator).tolist()
+
+
+class BagStore:
+    """Bags resident in HBM: uniform bags as one [n, K, D] tensor (gathered by index per step),
+    ragged bags as a list of device tensors concatenated per step."""
+
+    def __init__(self, bags, device):
+        self.device = device
+        lens = {int(b.shape[0]) for b in bags}
+        self.uniform = len(lens) == 1
+        self.lengths = [int(b.shape[0]) for b in bags]
+        if self.uniform:
+            self.data = torch.as_tensor(np.stack([np.asarray(b, dtype=np.float32) for b in bags])).to(device)
+        else:
+            self.data = [torch.as_tensor(np.asarray(b, dtype=np.float32)).to(device) for b in bags]
+
+    def batch(self, idx):
+        if self.uniform:
+            x = self.data[torch.as_tensor(idx, device=self.device)]
+            return x.reshape(-1, x.shape[-1]), BagOffsets.uniform(len(idx), x.shape[1], self.device)
+        xs = [self.data[i] for i in idx]
+        return torch.cat(xs), BagOffsets.from_lengths([self.lengths[i] for i in idx], self.device)
+
+
+def _make_optimizer(model, name, lr, wd):
+    cls = optim.AdamW if name.lower() == "adamw" else optim.Adam if name.lower() == "adam" else None
+    if cls is None:
+        raise ValueError(f"Unknown optimizer: {name}")
+    return cls(model.parameters(), lr=lr, weight_decay=wd)
+
+
+def _sync_step(opt, sync, world):
+    sync.finish()
+    opt.step(grad_scale=1.0 / world)
+
+
+# ----------------------------------------------------------------------------- MIL teacher
+@torch.no_grad()
+def eval_teacher(model, store, labels, chunk=64):
+    """bag_probs + mean per-bag CE over all bags (`01:247-260`)."""
+    model.eval()
+    probs, losses = [], []
+    n = len(labels)
+    for lo in range(0, n, chunk):
+        idx = list(range(lo, min(n, lo + chunk)))
+        x, offs = store.batch(idx)
+        out = model(x, offs)
+        y = torch.as_tensor(np.asarray(labels)[idx], device=x.device)
+        losses.append(ops.CrossEntropyFn.apply(out["bag_logits"], y, 0)[1].cpu())
+        probs.append(out["bag_probs"].cpu())
+    return torch.cat(probs).numpy(), float(torch.cat(losses).mean()) if losses else float("nan")
+
+
+def train_teacher_fold(model, train_bags, train_labels, val_bags, val_labels, *, optimizer="adamw", lr=2.2e-4,
+                       weight_decay=8.6e-4, epochs=200, patience=8, bags_per_step=1, seed=42, device=None, log=print,
+                       metric_fn=None):
+    """`01_train_mil_teacher.py:203-290` for one fold.  Returns dict(best_state_bacc, best_state_loss,
+    history).  Every rank draws the same sampler stream and takes its slice of each step's bags."""
+    from sklearn.metrics import balanced_accuracy_score
+    rank, world = dist_info()
+    device = device or next(model.parameters()).device
+    tr, va = BagStore(train_bags, device), BagStore(val_bags, device)
+    opt = _make_optimizer(model, optimizer, lr, weight_decay)
+    ddp.broadcast_parameters(opt.flat.data)
+    sync = ddp.GradSync(opt.flat.grad, world_size=world)
+    gen = torch.Generator().manual_seed(seed)
+    best = {"bacc": -np.inf, "loss": float("inf"), "state_bacc": None, "state_loss": None, "no_improve": 0}
+    history = []
+    per_step = bags_per_step * world
+    for epoch in range(1, epochs + 1):
+        model.train()
+        order = weighted_sample_indices(train_labels, gen)
+        for s in range(0, len(order), per_step):
+            glob = order[s:s + per_step]
+            lo, hi = ddp.shard_range(len(glob), rank, world)
+            mine = glob[lo:hi]
+            opt.zero_grad()
+            sync.reset()
+            if mine:
+                x, offs = tr.batch(mine)
+                out = model(x, offs)
+                y = torch.as_tensor(np.asarray(train_labels)[mine], device=device)
+                # mean over the GLOBAL step: local mean * (local / global count), summed by the all-reduce
+                loss = ops.cross_entropy(out["bag_logits"], y) * (len(mine) * world / len(glob))
+                loss.backward()
+            _sync_step(opt, sync, world)
+        probs, val_loss = eval_teacher(model, va, val_labels)
+        if len(val_labels) == 0:
+            break
+        pred = probs.argmax(axis=1)
+        bacc = balanced_accuracy_score(np.asarray(val_labels), pred)
+        if bacc > best["bacc"] + 1e-6:
+            best["bacc"], best["state_bacc"] = bacc, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        if val_loss < best["loss"] - 1e-6:
+            best["loss"], best["no_improve"] = val_loss, 0
+            best["state_loss"] = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        else:
+            best["no_improve"] += 1
+        extra = metric_fn(np.asarray(val_labels), probs) if metric_fn else {}
+        history.append({"epoch": epoch, "val_bacc": bacc, "val_loss": val_loss, **extra})
+        if rank == 0 and log:
+            log(f"    Epoch {epoch:03d}: Val BAcc: {bacc:.4f} (best: {best['bacc']:.4f})  | Val Loss: {val_loss:.4f} "
+                f"(best: {best['loss']:.4f} ) | Epochs no improve: {best['no_improve']}/{patience}")
+        if best["no_improve"] >= patience:
+            break
+    return {"best_state_bacc": best["state_bacc"], "best_state_loss": best["state_loss"], "history": history}
+
+
+@torch.no_grad()
+def collect_teacher_outputs(model, bags, labels, image_ids, device, chunk=64):
+    """`01_train_mil_teacher.py:69-87`: rows {image_id, label, patch_probs, attention, patch_embeddings}."""
+    import pandas as pd
+    model.eval()
+    store = BagStore(bags, device)
+    rows = []
+    for lo in range(0, len(bags), chunk):
+        idx = list(range(lo, min(len(bags), lo + chunk)))
+        x, offs = store.batch(idx)
+        out = model(x, offs)
+        pp, att = out["patch_probs"].cpu().numpy(), out["attention"].cpu().numpy()
+        for j, i in enumerate(idx):
+            a, b = int(offs.host[j]), int(offs.host[j + 1])
+            rows.append({"image_id": image_ids[i], "label": int(labels[i]), "patch_probs": pp[a:b], "attention": att[a:b],
+                         "patch_embeddings": np.asarray(bags[i], dtype=np.float32)})
+    return pd.DataFrame(rows)
+
+
+# ----------------------------------------------------------------------------- patch-graph GNN
+class GraphStore:
+    """Graph records resident in HBM with their normalised CSR built once (graphs are static across
+    epochs; the reference re-uploads x and edge_index every step, `05:340-343`)."""
+
+    def __init__(self, records, device, needs_graph=True):
+        self.device, self.records = device, records
+        self.x = [torch.as_tensor(np.asarray(r["x"], dtype=np.float32)).to(device) for r in records]
+        self.y = np.asarray([int(r["y"]) for r in records])
+        self.ei = [torch.as_tensor(np.asarray(r["edge_index"], dtype=np.int64)).to(device)
+                   if needs_graph and r.get("edge_index") is not None else None for r in records]
+        self.needs_graph = needs_graph
+        self._single = {}
+
+    def batch(self, idx):
+        xs = [self.x[i] for i in idx]
+        lens = [int(t.shape[0]) for t in xs]
+        offs = BagOffsets.from_lengths(lens, self.device)
+        if len(idx) == 1:
+            i = idx[0]
+            if self.needs_graph and i not in self._single:
+                self._single[i] = GraphBatch(self.ei[i], lens[0])
+            return xs[0], offs, self._single.get(i)
+        graph = None
+        if self.needs_graph:
+            ei = torch.cat([self.ei[i] + int(o) for i, o in zip(idx, offs.host[:-1])], dim=1)
+            graph = GraphBatch(ei, offs.total)
+        return torch.cat(xs), offs, graph
+
+
+def gnn_metrics(labels, scores, num_classes):
+    """`05_train_gnns.py:284-302` metric set (sklearn, as the reference)."""
+    from sklearn.metrics import accuracy_score, balanced_accuracy_score, precision_recall_fscore_support, roc_auc_score
+    pred = scores.argmax(axis=1)
+    try:
+        auc = roc_auc_score(labels, scores, multi_class="ovr", labels=np.arange(num_classes))
+    except ValueError:
+        auc = float("nan")
+    f1 = precision_recall_fscore_support(labels, pred, average="macro", zero_division=0)[2]
+    return {"accuracy": accuracy_score(labels, pred), "bacc": balanced_accuracy_score(labels, pred), "auc": auc,
+            "macro_f1": f1}
+
+
+@torch.no_grad()
+def evaluate_gnn(model, store, num_classes, chunk=32):
+    model.eval()
+    n = len(store.x)
+    if n == 0:
+        return {k: float("nan") for k in ("loss", "accuracy", "bacc", "auc", "macro_f1")}
+    scores, losses = [], []
+    for lo in range(0, n, chunk):
+        idx = list(range(lo, min(n, lo + chunk)))
+        x, offs, g = store.batch(idx)
+        probs, _ = model(x, offsets=offs, graph=g)
+        y = torch.as_tensor(store.y[idx], device=x.device)
+        losses.append(ops.CrossEntropyFn.apply(probs, y, 1)[1].cpu())      # CE(log(p + 1e-9)), 05:282
+        scores.append(probs.cpu())
+    scores = torch.cat(scores).numpy()
+    return {"loss": float(torch.cat(losses).mean()), **gnn_metrics(store.y, scores, num_classes)}
+
+
+def train_gnn_fold(model, train_records, val_records, test_records, *, lr=1e-4, weight_decay=1e-4, epochs=1,
+                   patience=16, min_delta=1e-6, graphs_per_step=1, num_classes=7, device=None, rng=None):
+    """`05_train_gnns.py:305-358`: AdamW, epoch order = np.random.permutation, best state by validation
+    balanced accuracy.  The class weights of `05:328-331` cancel for single-sample CE and
+    batched steps keep the unweighted per-graph mean.  Returns (val_metrics, test_metrics, best_epoch)."""
+    rank, world = dist_info()
+    device = device or next(model.parameters()).device
+    needs = model.gnn_type != "mlp"
+    tr, va, te = (GraphStore(r, device, needs) for r in (train_records, val_records, test_records))
+    opt = optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
+    ddp.broadcast_parameters(opt.flat.data)
+    sync = ddp.GradSync(opt.flat.grad, world_size=world)
+    rng = rng or np.random
+    best_state, best_bacc, no_imp, best_epoch = None, -np.inf, 0, 0
+    per_step = graphs_per_step * world
+    for epoch in range(1, epochs + 1):
+        model.train()
+        order = rng.permutation(len(train_records)).tolist()
+        for s in range(0, len(order), per_step):
+            glob = order[s:s + per_step]
+            lo, hi = ddp.shard_range(len(glob), rank, world)
+            mine = glob[lo:hi]
+            opt.zero_grad()
+            sync.reset()
+            if mine:
+                x, offs, g = tr.batch(mine)
+                probs, _ = model(x, offsets=offs, graph=g)
+                y = torch.as_tensor(tr.y[mine], device=device)
+                loss = ops.cross_entropy_from_probs(probs, y) * (len(mine) * world / len(glob))
+                loss.backward()
+            _sync_step(opt, sync, world)
+        vm = evaluate_gnn(model, va, num_classes)
+        if vm["bacc"] > best_bacc + min_delta:
+            best_bacc, no_imp, best_epoch = vm["bacc"], 0, epoch
+            best_state = copy.deepcopy(model.state_dict())
+        else:
+            no_imp += 1
+        if no_imp >= patience:
+            break
+    if best_state is not None:
+        model.load_state_dict(best_state)
+    return evaluate_gnn(model, va, num_classes), evaluate_gnn(model, te, num_classes), best_epoch
