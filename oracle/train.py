@@ -1,0 +1,67 @@
+"""Batched CPU training loops (oracle / test infrastructure) with the SAME batching, sampler
+stream, counter-based dropout words and AdamW as the HIP loops in
+``multimodal-isic_amd/isic_hip/train.py`` -- the like-for-like partner of the AUROC-parity
+check.  With ``per_step=1`` they are the reference loops
+(`01_train_mil_teacher.py:235-290`, `05_train_gnns.py:336-358`)."""
+from __future__ import annotations
+
+from collections import Counter
+
+import numpy as np
+import torch
+
+from . import gnn, metrics, mil
+
+
+def weighted_sample_indices(labels, generator):
+    """torch ``WeightedRandomSampler(1/class_count, n, replacement=True)`` (`01:189-193`) draws
+    ``torch.multinomial(weights, n, True, generator)``."""
+    counts = Counter(np.asarray(labels).tolist())
+    w = torch.tensor([1.0 / counts[int(l)] for l in labels], dtype=torch.float64)
+    return torch.multinomial(w, len(labels), replacement=True, generator=generator).tolist()
+
+
+def train_teacher(p, train_bags, train_labels, val_bags, val_labels, *, lr, weight_decay, epochs, per_step, seed,
+                  dropout=0.0, dropout_seed=0):
+    q = {k: torch.nn.Parameter(v.detach().clone()) for k, v in p.items()}
+    opt = torch.optim.AdamW(list(q.values()), lr=lr, weight_decay=weight_decay)
+    gen = torch.Generator().manual_seed(seed)
+    step, hist = 0, []
+    for _ in range(epochs):
+        order = weighted_sample_indices(train_labels, gen)
+        for s in range(0, len(order), per_step):
+            idx = order[s:s + per_step]
+            x = torch.cat([torch.as_tensor(train_bags[i]) for i in idx])
+            offs = np.concatenate([[0], np.cumsum([train_bags[i].shape[0] for i in idx])])
+            drop = {"p": dropout, "seed": dropout_seed, "stream": step * 1024} if dropout > 0 else None
+            opt.zero_grad()
+            out = mil.teacher_forward_batched(q, x, offs, drop=drop)
+            mil.batched_loss(out["bag_logits"], torch.as_tensor(np.asarray(train_labels)[idx])).backward()
+            opt.step()
+            step += 1
+        with torch.no_grad():
+            probs = np.stack([mil.teacher_forward(q, torch.as_tensor(b))["bag_probs"].numpy() for b in val_bags])
+        hist.append({"val_auc": metrics.roc_auc_ovr_macro(np.asarray(val_labels), probs),
+                     "val_bacc": metrics.balanced_accuracy(np.asarray(val_labels), probs.argmax(axis=1)), "probs": probs})
+    return {k: v.detach() for k, v in q.items()}, hist
+
+
+def train_gnn(p, cfg, train_records, val_records, *, lr, weight_decay, epochs, orders, num_classes=7):
+    """Per-graph steps in the given epoch ``orders`` (the reference draws them from np.random,
+    `05:338`); eval-mode metrics on the validation records after each epoch."""
+    q = {k: torch.nn.Parameter(v.detach().clone()) for k, v in p.items()}
+    opt = torch.optim.AdamW(list(q.values()), lr=lr, weight_decay=weight_decay)
+    hist = []
+    for ep in range(epochs):
+        for i in orders[ep]:
+            r = train_records[int(i)]
+            opt.zero_grad()
+            out = gnn.graphmil_forward(q, cfg, torch.as_tensor(r["x"]), torch.as_tensor(r["edge_index"]))
+            gnn.graph_loss(out["probs"], r["y"]).backward()
+            opt.step()
+        with torch.no_grad():
+            probs = np.stack([gnn.graphmil_forward(q, cfg, torch.as_tensor(r["x"]), torch.as_tensor(r["edge_index"]))["probs"].numpy()
+                              for r in val_records])
+        y = np.asarray([r["y"] for r in val_records])
+        hist.append({"val_auc": metrics.roc_auc_ovr_macro(y, probs, num_classes), "probs": probs})
+    return {k: v.detach() for k, v in q.items()}, hist
