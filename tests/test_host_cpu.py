@@ -1,0 +1,131 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol that
+include/isic_hip.h declares (no compute calls without a GPU), the header parser, bag offsets,
+counter-based dropout bookkeeping, graph builders that live on the host, and that the product
+refuses CPU tensors instead of silently falling back."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+from oracle import philox
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from isic_hip import lib
+    L = lib.lib()
+    text = open(os.path.join(ROOT, "include", "isic_hip.h")).read()
+    declared = set(re.findall(r"\b(isic_\w+)\s*\(", text))
+    assert declared == set(L.protos), declared ^ set(L.protos)
+    assert len(declared) >= 35
+    cdll = ctypes.CDLL(lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(cdll, name), name
+    assert L.fn["isic_abi_version"]() == 1
+    assert L.fn["isic_target_arch"]() == b"gfx950"
+    # argument validation happens before any device work: usable without a GPU
+    assert L.fn["isic_gcn_csr_workspace_bytes"](10, 20) == (6 * 10 + 2 * 30 + 64) * 4
+    assert L.fn["isic_gemm_f32"](0, 0, -1, 4, 4, None, 4, None, 4, None, 4, None, 0, 0.0, None) == -1
+    assert L.fn["isic_conv2d_igemm_bf16"](1, 1, 1, 1, 8, 8, 48, 8, 8, 64, 3, 3, 1, 1, 1, None) == -2   # Cin % 64
+
+
+def test_header_prototypes_parse():
+    from isic_hip import lib
+    protos = lib.parse_header()
+    rt, args = protos["isic_adam_step"]
+    assert rt is ctypes.c_int and [a[1] for a in args][-1] == "stream"
+    assert [a[0] for a in args][:5] == [ctypes.c_void_p] * 4 + [ctypes.c_int64]
+    assert protos["isic_gcn_csr_workspace_bytes"][0] is ctypes.c_size_t
+    with pytest.raises(TypeError):
+        lib.call("isic_colsum_f32", 1, 2)
+
+
+def test_cpu_tensors_are_rejected_everywhere():
+    import utils_g_mil
+    from gnn_models import GraphMIL
+    from isic_hip.lib import IsicHipError
+    from model import MultiModalMILNet
+    with pytest.raises(IsicHipError):
+        utils_g_mil.AttentionMIL(8, 4, 4, 0.0, 3)(torch.zeros(5, 8))
+    with pytest.raises(IsicHipError):
+        GraphMIL(8, "mlp", 8, 1, 0.0, att_dim=4, classifier_dim=4, classifier_light=True)(torch.zeros(5, 8))
+    with pytest.raises(IsicHipError):
+        MultiModalMILNet(hidden_dim=8, att_dim=4, radiomics_dim=4, encoder_layers=((64, 1),))(torch.zeros(2, 2, 3, 32, 32), torch.zeros(2, 4))
+    with pytest.raises(NotImplementedError):
+        GraphMIL(8, "gat")
+    with pytest.raises(ValueError):
+        GraphMIL(8, "nope")
+
+
+def test_state_dict_surface_matches_reference_names():
+    import utils_g_mil
+    from gnn_models import GraphMIL
+    from helpers import shapes_from_blob
+    for fixture, make in (
+        ("teacher_ref.npz", lambda: utils_g_mil.AttentionMIL_teacher(768, 128, 64, 0.5, 7)),
+        ("attmil_ref.npz", lambda: utils_g_mil.AttentionMIL(768, 128, 64, 0.5, 7)),
+        ("graphmil_mlp_ref.npz", lambda: GraphMIL(768, "mlp", 128, 2, 0.5, att_dim=128, att_heads=4, pool_dropout=0.2,
+                                                   classifier_dim=128, classifier_light=True)),
+    ):
+        want = shapes_from_blob(load_golden(fixture)["names"])
+        got = {k: tuple(v.shape) for k, v in make().state_dict().items()}
+        assert list(got.items()) == list(want.items()), fixture
+
+
+def test_dropout_spec_matches_oracle_definition():
+    from isic_hip.ops import DropoutSpec
+    for p in (0.0, 0.2, 0.5, 0.71, 0.999):
+        s = DropoutSpec(p, seed=5, stream=9)
+        assert s.threshold == (philox.dropout_threshold(p) if p > 0 else 0)
+        if p > 0:
+            assert s.scale == float(philox.dropout_scale(p))
+    with pytest.raises(ValueError):
+        DropoutSpec(1.0)
+    # known-answer: Philox4x32-10 of the all-zero counter/key (Random123 reference vector)
+    z = np.zeros(1, dtype=np.uint32)
+    r = philox.philox4x32_10(z, z, z, z, 0, 0)
+    assert [int(v[0]) for v in r] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+
+
+def test_bag_offsets_and_sharding():
+    from isic_hip.bags import BagOffsets
+    from isic_hip.ddp import shard_range
+    o = BagOffsets.from_lengths([3, 0, 5], "cpu")
+    assert o.num_bags == 3 and o.max_bag == 5 and o.total == 8 and o.host.tolist() == [0, 3, 3, 8]
+    assert BagOffsets.uniform(4, 7, "cpu").host.tolist() == [0, 7, 14, 21, 28]
+    with pytest.raises(ValueError):
+        BagOffsets([1, 2], "cpu")
+    for n, w in ((10, 4), (3, 8), (64, 8)):
+        spans = [shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_host_side_graph_builders_golden():
+    import build_graphs as bg
+    import utils_g_mil
+    g = load_golden("graphs.npz")
+    assert np.array_equal(bg._grid_edge_index(False).numpy(), g["grid4"])
+    assert np.array_equal(bg._grid_edge_index(True).numpy(), g["grid8"])
+    for seed, r in ((42, 4), (10042, 1), (20049, 16)):
+        assert np.array_equal(bg._random_edge_index(196, r, seed).numpy(), g[f"random.{seed}.{r}"])
+    for diag in (False, True):
+        _, _, ei, ew = utils_g_mil.build_graph(torch.zeros(196, 4), "grid", connect_diagonals=diag)
+        assert np.array_equal(ei.numpy(), g[f"gridadj{int(diag)}.edge_index"])
+        np.testing.assert_allclose(ew.numpy(), g[f"gridadj{int(diag)}.edge_weight"], rtol=1e-6)
+    with pytest.raises(ValueError):
+        utils_g_mil.build_grid_adj(10)
+    assert bg._knn_edge_index(torch.zeros(1, 4), 3).shape == (2, 0)
+
+
+def test_early_stopping_counts_down():
+    from net_utils import EarlyStopping
+    es = EarlyStopping(patience=2)
+    m = torch.nn.Linear(2, 2)
+    assert es(1.0, m) is False and es.counter == 2
+    assert es(1.5, m) is False and es.counter == 1
+    assert es(1.2, m) is True and es.get_best_model_state() is not None
