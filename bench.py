@@ -37,7 +37,7 @@ WORKLOAD = ("ISIC-shaped attention-MIL: 256 bags x 64x224x224 patches + 128-d ra
 def conv_flops(spec_args):
     """Algorithmic FLOPs of one isic_conv2d_igemm_bf16 launch (2*M*Cout*K of the convolution it
     implements; for a data-gradient launch that is the forward convolution's count)."""
-    (_in, _w, _out, N, Hin, Win, Cin, Hout, Wout, Cout, Kh, Kw, up, down, pad) = spec_args
+    (_in, _w, _out, N, Hin, Win, Cin, Hout, Wout, Cout, Kh, Kw, up, down, pad) = spec_args[:15]
     if down == 1:      # forward: out pixels x Cout x (Kh*Kw*Cin)
         return 2.0 * N * Hout * Wout * Cout * Kh * Kw * Cin
     # dgrad with stride `down`: only 1/down^2 of the taps hit a real dY pixel

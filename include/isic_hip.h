@@ -176,17 +176,28 @@ int isic_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* va
  *
  * isic_conv2d_igemm_bf16: implicit-GEMM convolution, forward AND data gradient:
  *   out[n,ho,wo,co] = sum_{kh,kw,ci} in[n, (ho*up+kh-pad)/down, (wo*up+kw-pad)/down, ci] * w[co,kh,kw,ci]
- *   (taps whose source pixel is fractional or outside the image contribute zero)
+ *                     (+ addend[n,ho,wo,co], added in fp32 before the single rounding to bf16)
+ *   (taps whose source pixel is fractional or outside the image contribute zero; a down = 2
+ *   launch is split by output parity so that only integral taps are visited)
  *   forward: up = stride, down = 1, pad = padding, w = bf16 W[co][kh][kw][ci]
  *   dgrad:   up = 1, down = stride, pad = k-1-padding, in = dY, w = W flipped+transposed [ci][kh][kw][co]
- * Cin and Cout must be multiples of 64; down in {1,2,4}. */
+ * Optional fused BatchNorm statistics (down = 1 only): per-channel sum / sum of squares of the
+ * rounded outputs are ADDED (fp64 atomics) into stat_sum/stat_sumsq[stat_slots][Cout] (zeroed by
+ * the caller; isic_bn_finalize sums the slots).
+ * Cin and Cout must be multiples of 64; down in {1,2}. */
 int isic_conv2d_igemm_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int Hin, int Win, int Cin,
-                           int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad, void* stream);
+                           int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad,
+                           const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots, void* stream);
+/* developer knob for A/B timing of the implicit-GEMM main loop (0 = one LDS stage, 1 = two). */
+int isic_debug_set_conv_variant(int v);
 /* dW[co][kh][kw][ci] (fp32, ACCUMULATED with atomics into the caller's zeroed or
  * running gradient) = sum_{n,ho,wo} dY[n,ho,wo,co] * X[n,ho*stride+kh-pad,wo*stride+kw-pad,ci].
- * N*Hout*Wout < 2^24 per call (the caller chunks larger batches). */
+ * workspace: isic_conv2d_wgrad_workspace_bytes(N, Hout, Wout) bytes (per-pixel
+ * source-offset table, rebuilt by every call). */
+size_t isic_conv2d_wgrad_workspace_bytes(int N, int Hout, int Wout);
 int isic_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dw, int N, int Hin, int Win, int Cin,
-                           int Hout, int Wout, int Cout, int Kh, int Kw, int stride, int pad, void* stream);
+                           int Hout, int Wout, int Cout, int Kh, int Kw, int stride, int pad, void* workspace,
+                           size_t workspace_bytes, void* stream);
 /* fp32 master weights [O][Kh][Kw][I] -> bf16 forward copy (same order) and bf16
  * dgrad copy [I][Kh][Kw][O] with both taps flipped (either may be NULL). */
 int isic_conv_weight_prep_bf16(const float* w_krsc, uint16_t* w_fwd, uint16_t* w_dgrad, int O, int I, int Kh, int Kw,
@@ -205,10 +216,11 @@ int isic_conv_stem_pack_bf16(const float* w_krsc, uint16_t* w_stem, void* stream
 int isic_nchw_to_nhwc4_bf16(const void* in, int in_is_bf16, uint16_t* out, int N, int C, int H, int W, void* stream);
 
 /* BatchNorm2d, training mode, NHWC bf16.  stats: per-channel sum / sum of squares
- * in fp64 (zeroed by the caller); finalize: scale = gamma*rstd, shift = beta -
- * mean*scale, running stats updated with `momentum` (unbiased variance). */
+ * in fp64 (zeroed by the caller), as sum[nslots][C] partial rows; finalize adds the
+ * slots: scale = gamma*rstd, shift = beta - mean*scale, running stats updated with
+ * `momentum` (unbiased variance). */
 int isic_bn_stats_bf16(const uint16_t* x, int64_t rows, int C, double* sum, double* sumsq, void* stream);
-int isic_bn_finalize(const double* sum, const double* sumsq, int64_t rows, int C, const float* gamma,
+int isic_bn_finalize(const double* sum, const double* sumsq, int nslots, int64_t rows, int C, const float* gamma,
                      const float* beta, float eps, float momentum, float* scale, float* shift, float* mean,
                      float* rstd, float* running_mean, float* running_var, void* stream);
 /* eval mode: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale */
@@ -217,17 +229,19 @@ int isic_bn_eval_affine(const float* gamma, const float* beta, const float* runn
 /* y = relu?(x*scale + shift + residual) */
 int isic_bn_apply_bf16(const uint16_t* x, const float* scale, const float* shift, const uint16_t* residual,
                        uint16_t* y, int64_t rows, int C, int relu, void* stream);
-/* backward in two passes.  reduce: dz = dy * (y > 0 if relu); dbeta = sum dz,
+/* backward in two passes.  The ReLU mask comes from y, or -- when scale/shift (the
+ * forward affine) are given and there was no residual -- is recomputed as
+ * x*scale+shift > 0 so that y is not read at all.  reduce: dz = dy * mask; dbeta = sum dz,
  * dgamma = sum dz*xhat (fp64, zeroed by the caller).  apply: dx = gamma*rstd *
  * (dz - dbeta/rows - xhat*dgamma/rows); d_residual = dz (optional); the fp32
  * parameter gradients get += dgamma/dbeta (optional). */
 int isic_bn_bwd_reduce_bf16(const uint16_t* dy, const uint16_t* x, const uint16_t* y, const float* mean,
-                            const float* rstd, int64_t rows, int C, int relu, double* dgamma, double* dbeta,
-                            void* stream);
+                            const float* rstd, int64_t rows, int C, int relu, const float* scale,
+                            const float* shift, double* dgamma, double* dbeta, void* stream);
 int isic_bn_bwd_apply_bf16(const uint16_t* dy, const uint16_t* x, const uint16_t* y, const float* mean,
                            const float* rstd, const float* gamma, const double* dgamma, const double* dbeta,
-                           int64_t rows, int C, int relu, uint16_t* dx, uint16_t* d_residual, float* dgamma_f32,
-                           float* dbeta_f32, void* stream);
+                           int64_t rows, int C, int relu, const float* scale, const float* shift, uint16_t* dx,
+                           uint16_t* d_residual, float* dgamma_f32, float* dbeta_f32, void* stream);
 /* MaxPool 3x3/2 pad 1 (first maximum wins, like torch); argmax[N,Ho,Wo,C] holds the
  * winning tap kh*3+kw for the backward pass. */
 int isic_maxpool3x3s2_fwd_bf16(const uint16_t* x, uint16_t* y, uint8_t* argmax, int N, int H, int W, int C, int Ho,

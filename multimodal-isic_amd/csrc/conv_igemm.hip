@@ -1,6 +1,6 @@
 // Implicit-GEMM convolution on bf16 MFMA (gfx950), NHWC activations, [Cout][Kh][Kw][Cin] weights.
 //
-//   out[m, co] = sum_{kh,kw,ci} in[pix(m,kh,kw), ci] * w[co, kh, kw, ci]      m = (n, ho, wo)
+//   out[m, co] = sum_{kh,kw,ci} in[pix(m,kh,kw), ci] * w[co, kh, kw, ci]  (+ addend[m, co])   m = (n, ho, wo)
 //
 // GEMM view: M = N*Hout*Wout (pixels), N = Cout, K = Kh*Kw*Cin with BOTH operands K-contiguous
 // (NHWC rows are channel-contiguous, weights are stored K-major), which is exactly the operand
@@ -8,8 +8,16 @@
 //
 // The same kernel is the forward pass (up = stride, down = 1) and the data-gradient pass
 // (up = 1, down = stride, flipped/transposed weights): the source pixel of tap (kh,kw) for output
-// (ho,wo) is ((ho*up + kh - pad)/down, (wo*up + kw - pad)/down) and taps whose source is fractional
-// or outside the image contribute zero.
+// (ho,wo) is ((ho*up + kh - pad)/down, (wo*up + kw - pad)/down).  A stride-2 data gradient is
+// split by output-pixel parity into 4 launches, each visiting only the taps whose source pixel is
+// integral for that parity class (9 taps in total instead of 36 for a 3x3 kernel).
+//
+// Fused epilogues (all optional):
+//   * addend: out = conv + addend, added in fp32 BEFORE the single rounding to bf16 (the residual
+//     gradient join of a ResNet block: d_x = dgrad(conv1) + d_residual);
+//   * BatchNorm statistics: per-channel sum / sum of squares of the bf16-rounded outputs of the
+//     tile, accumulated with fp64 atomics into one of `stat_slots` partial rows (slot =
+//     blockIdx.x % slots) -- replaces a full read pass over the conv output.
 //
 // The reference has no convolution kernel of its own (its encoder is an un-vendored ConvMAE run
 // through torch, save_latent.py:42-60); BASELINE.json configs[1] names ResNet-18, whose layer table
@@ -17,8 +25,9 @@
 //
 // Structure: 256 threads = 4 waves; block tile BM x BN (256x64 as 4x1 waves for Cout = 64,
 // 128x128 as 2x2 waves otherwise), each wave a 64x64 sub-tile = 4x4 MFMA tiles (64 accumulator
-// VGPRs); BK = 64 = one (kh,kw) tap x 64 channels.  Global -> registers -> LDS staging with the next
-// K-tile's loads issued before the current tile's MFMAs; LDS rows are 128 B with a 16-byte-chunk XOR
+// VGPRs); BK = 64 = one (kh,kw) tap x 64 channels.  Global -> registers -> LDS staging into TWO LDS
+// buffers: the next K-tile's global loads are issued before the current tile's MFMAs and written to
+// the other buffer after them, one barrier per K-tile.  LDS rows are 128 B with a 16-byte-chunk XOR
 // swizzle (chunk ^= row & 7) so the ds_read_b128 fragment reads are conflict-free; the epilogue
 // transposes through LDS so every global store is a full 16-byte-per-lane row segment.
 #include "common.h"
@@ -31,75 +40,95 @@ struct ConvArgs {
   const unsigned short* in;
   const unsigned short* w;
   unsigned short* out;
+  const unsigned short* addend;
+  double* stat_sum;
+  double* stat_sumsq;
+  int stat_slots;
   int N, Hin, Win, Cin, Hout, Wout, Cout, Kh, Kw, up, down_shift, pad;
-  int M;        // N*Hout*Wout
-  int Ktiles;   // Kh*Kw*Cin/64
+  // output sub-grid of this launch: (ho, wo) = (oh0 + ostep*hs, ow0 + ostep*ws), hs < Hs, ws < Ws
+  int Hs, Ws, oh0, ow0, ostep;
+  // taps of this launch: kh = kh0 + kstep*i (i < nkh), kw = kw0 + kstep*j (j < nkw)
+  int kh0, kw0, kstep, nkh, nkw;
+  int M;        // N*Hs*Ws
+  int Ktiles;   // nkh*nkw*Cin/64
   int ctiles;   // Cin/64
+  unsigned long long magic_hw, magic_w;   // floor(2^40/d)+1 for d = Hs*Ws and d = Ws (M < 2^24)
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+__device__ __forceinline__ unsigned fastdiv40(unsigned n, unsigned long long magic) {
+  return (unsigned)(((unsigned long long)n * magic) >> 40);
+}
+// bit t set iff lo <= base + t < hi, for t in [0, cnt)  (cnt <= 16)
+__device__ __forceinline__ unsigned range_mask(int base, int lo, int hi, int cnt) {
+  int t0 = lo - base, t1 = hi - base;
+  t0 = t0 < 0 ? 0 : t0;
+  t1 = t1 > cnt ? cnt : t1;
+  return t1 > t0 ? (((1u << t1) - 1u) & ~((1u << t0) - 1u)) : 0u;
+}
+
+__device__ __forceinline__ float bfbits(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool DB>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   static_assert(BM == WAVES_M * 64 && BN == WAVES_N * 64, "64x64 per wave");
-  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int CPAD = BN + 8;  // epilogue row stride (elements)
-  constexpr int C_BYTES = BM * CPAD * 2;
-  constexpr int LDS_BYTES = (A_BYTES + B_BYTES) > C_BYTES ? (A_BYTES + B_BYTES) : C_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
-  unsigned char* As = smem;
-  unsigned char* Bs = smem + A_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // (DB ? 2 : 1)*STAGE, >= C tile
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
-  // ---- staging assignment: 16-byte chunk `sc` of rows `sr + 32*i`
+  // ---- staging assignment: 16-byte chunk `sc` of rows `sr + 32*i`.
+  // Everything that depends on the ROW is computed once, before the K loop: the source pixel of tap
+  // (ti,tj) is (hrow + dh(ti), wrow + dw(tj)) with a per-tap uniform (dh, dw), so a row carries its
+  // element offset at (dh, dw) = (0, 0) plus one validity bit per tap row / tap column; inside the K loop a
+  // row costs two bit tests, one add and one select.
   constexpr int AROWS = BM / 32, BROWS = BN / 32;
   const int sr = tid >> 3, sc = tid & 7;
-  int a_base[AROWS];   // element offset of pixel (n, 0, 0) channel 0 ; -1 if row >= M
-  int a_hb[AROWS], a_wb[AROWS];
+  const int ds_ = a.down_shift;
+  // per-tap uniform offsets: dh(ti) = (oh0*up + kh - pad) >> ds  (exact for the taps of this parity class)
+  const int dh0 = (a.oh0 * a.up + a.kh0 - a.pad) >> ds_, dw0 = (a.ow0 * a.up + a.kw0 - a.pad) >> ds_;
+  constexpr int dstep = 1;            // kstep >> down_shift: 1 in both modes (kstep = down)
+  const int rstep = (a.ostep * a.up) >> ds_;   // source rows per sub-grid row: stride (fwd) or 1 (dgrad class)
+  int a_off[AROWS];          // element offset of (n, hrow, wrow, 0); meaningless when no tap is valid
+  unsigned a_vh[AROWS], a_vw[AROWS];   // bit ti: 0 <= hrow + dh0 + dstep*ti < Hin ; bit tj likewise for columns
 #pragma unroll
   for (int i = 0; i < AROWS; ++i) {
     const int m = m0 + sr + 32 * i;
+    a_off[i] = 0; a_vh[i] = 0u; a_vw[i] = 0u;
     if (m < a.M) {
-      const int hw = a.Hout * a.Wout;
-      const int n = m / hw, r = m - n * hw;
-      const int ho = r / a.Wout, wo = r - ho * a.Wout;
-      a_base[i] = n * a.Hin * a.Win;
-      a_hb[i] = ho * a.up - a.pad;
-      a_wb[i] = wo * a.up - a.pad;
-    } else {
-      a_base[i] = -1; a_hb[i] = 0; a_wb[i] = 0;
+      const int n = (int)fastdiv40((unsigned)m, a.magic_hw);
+      const int r = m - n * (a.Hs * a.Ws);
+      const int hs = (int)fastdiv40((unsigned)r, a.magic_w), ws = r - hs * a.Ws;
+      const int hrow = hs * rstep, wrow = ws * rstep;
+      a_off[i] = ((n * a.Hin + hrow) * a.Win + wrow) * a.Cin + sc * 8;
+      a_vh[i] = range_mask(hrow + dh0, 0, a.Hin, a.nkh);     // dstep == 1
+      a_vw[i] = range_mask(wrow + dw0, 0, a.Win, a.nkw);
     }
   }
-  const int dmask = (1 << a.down_shift) - 1;
   const size_t Ktot = (size_t)a.Kh * a.Kw * a.Cin;
+  const unsigned short* wrow_ptr[BROWS];
+#pragma unroll
+  for (int i = 0; i < BROWS; ++i) wrow_ptr[i] = a.w + (size_t)(n0 + sr + 32 * i) * Ktot + sc * 8;
 
-  u32x4 ra[AROWS], rb[BROWS];
-  auto gload = [&](int kt) {
+  u32x4 ra0[AROWS], rb0[BROWS];
+  auto gload = [&](int kt, u32x4 (&ra)[AROWS], u32x4 (&rb)[BROWS]) {
     const int tap = kt / a.ctiles, c0 = (kt - tap * a.ctiles) * BK;
-    const int kh = tap / a.Kw, kw = tap - kh * a.Kw;
+    const int ti = tap / a.nkw, tj = tap - ti * a.nkw;
+    const int toff = ((dh0 + dstep * ti) * a.Win + (dw0 + dstep * tj)) * a.Cin + c0;          // uniform
+    const int koff = ((a.kh0 + a.kstep * ti) * a.Kw + (a.kw0 + a.kstep * tj)) * a.Cin + c0;     // uniform
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
-      const int hn = a_hb[i] + kh, wn_ = a_wb[i] + kw;
-      const int hi = hn >> a.down_shift, wi = wn_ >> a.down_shift;
-      const bool ok = a_base[i] >= 0 && hn >= 0 && wn_ >= 0 && ((hn | wn_) & dmask) == 0 && hi < a.Hin && wi < a.Win;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (ok) {
-        const size_t off = ((size_t)(a_base[i] + hi * a.Win + wi)) * a.Cin + c0 + sc * 8;
-        v = *reinterpret_cast<const u32x4*>(a.in + off);
-      }
+      if (((a_vh[i] >> ti) & (a_vw[i] >> tj)) & 1u) v = *reinterpret_cast<const u32x4*>(a.in + (a_off[i] + toff));
       ra[i] = v;
     }
 #pragma unroll
-    for (int i = 0; i < BROWS; ++i) {
-      const int co = n0 + sr + 32 * i;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (co < a.Cout) v = *reinterpret_cast<const u32x4*>(a.w + (size_t)co * Ktot + (size_t)kt * BK + sc * 8);
-      rb[i] = v;
-    }
+    for (int i = 0; i < BROWS; ++i) rb[i] = *reinterpret_cast<const u32x4*>(wrow_ptr[i] + koff);
   };
-  auto lstore = [&]() {
+  auto lstore = [&](unsigned char* As, unsigned char* Bs, const u32x4 (&ra)[AROWS], const u32x4 (&rb)[BROWS]) {
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       const int r = sr + 32 * i;
@@ -119,12 +148,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fg = lane >> 4;
-  gload(0);
-  for (int kt = 0; kt < a.Ktiles; ++kt) {
-    __syncthreads();
-    lstore();
-    __syncthreads();
-    if (kt + 1 < a.Ktiles) gload(kt + 1);
+  auto compute = [&](const unsigned char* As, const unsigned char* Bs) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[4], bfr[4];
@@ -139,31 +163,115 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
+  };
+  if (DB) {
+    // variant 1: two LDS stages, one register set, one barrier per K-tile
+    if (a.Ktiles > 0) {   // a parity class of a strided data gradient can have no tap at all
+      gload(0, ra0, rb0);
+      lstore(smem, smem + A_BYTES, ra0, rb0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < a.Ktiles; ++kt) {
+      unsigned char* As = smem + (kt & 1) * STAGE;
+      const bool more = kt + 1 < a.Ktiles;
+      if (more) gload(kt + 1, ra0, rb0);
+      compute(As, As + A_BYTES);
+      if (more) {
+        unsigned char* An = smem + ((kt + 1) & 1) * STAGE;
+        lstore(An, An + A_BYTES, ra0, rb0);
+      }
+      __syncthreads();
+    }
+  } else {
+    // variant 0: one LDS stage, next tile's global loads in flight during the MFMAs
+    if (a.Ktiles > 0) gload(0, ra0, rb0);
+    for (int kt = 0; kt < a.Ktiles; ++kt) {
+      __syncthreads();                      // previous tile fully consumed
+      lstore(smem, smem + A_BYTES, ra0, rb0);
+      __syncthreads();
+      if (kt + 1 < a.Ktiles) gload(kt + 1, ra0, rb0);
+      compute(smem, smem + A_BYTES);
+    }
+    __syncthreads();
   }
 
-  // ---- epilogue: accumulators -> bf16 -> LDS [BM][CPAD] -> 16-byte row segments to global
-  __syncthreads();
+  // ---- epilogue.  The MFMAs were issued as D[co][pixel] = W * X^T, so lane (fg, fr) holds, for MFMA tile
+  // (i, j), the FOUR CONSECUTIVE output channels co = j*16 + fg*4 + {0..3} of pixel i*16 + fr: one packed
+  // 8-byte LDS store per tile instead of four 2-byte ones.
   unsigned short* Cs = reinterpret_cast<unsigned short*>(smem);
+  constexpr int CHUNKS = BN / 8;  // 16-byte chunks per output row
+  auto out_index = [&](int m) -> size_t {   // flat pixel index of sub-grid row m in the full output
+    const int n = (int)fastdiv40((unsigned)m, a.magic_hw);
+    const int r = m - n * (a.Hs * a.Ws);
+    const int hs = (int)fastdiv40((unsigned)r, a.magic_w), ws = r - hs * a.Ws;
+    return ((size_t)n * a.Hout + (a.oh0 + a.ostep * hs)) * a.Wout + (a.ow0 + a.ostep * ws);
+  };
+  const bool dense = (a.ostep == 1 && a.Hs == a.Hout && a.Ws == a.Wout);
+  const int crow0 = (wm * 64 + fr) * CPAD + wn * 64 + fg * 4;     // element index of tile (0,0)'s 4 values
+  if (a.addend) {
+    // stage the addend tile (coalesced), add in fp32 in the accumulator domain: ONE rounding
+    for (int idx = tid; idx < BM * CHUNKS; idx += 256) {
+      const int row = idx / CHUNKS, ch = idx - row * CHUNKS;
+      const int m = m0 + row;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (m < a.M) v = *reinterpret_cast<const u32x4*>(a.addend + (dense ? (size_t)m : out_index(m)) * a.Cout + n0 + ch * 8);
+      *reinterpret_cast<u32x4*>(Cs + row * CPAD + ch * 8) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(Cs + crow0 + i * 16 * CPAD + j * 16);
+        acc[i][j][0] += __uint_as_float(v[0] << 16);
+        acc[i][j][1] += __uint_as_float(v[0] & 0xFFFF0000u);
+        acc[i][j][2] += __uint_as_float(v[1] << 16);
+        acc[i][j][3] += __uint_as_float(v[1] & 0xFFFF0000u);
+      }
+    __syncthreads();
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = wm * 64 + i * 16 + fg * 4 + r;
-        const int col = wn * 64 + j * 16 + fr;
-        Cs[row * CPAD + col] = f32_to_bf16_bits(acc[i][j][r]);
-      }
+    for (int j = 0; j < 4; ++j) {
+      u32x2 v;
+      v[0] = (unsigned)f32_to_bf16_bits(acc[i][j][0]) | ((unsigned)f32_to_bf16_bits(acc[i][j][1]) << 16);
+      v[1] = (unsigned)f32_to_bf16_bits(acc[i][j][2]) | ((unsigned)f32_to_bf16_bits(acc[i][j][3]) << 16);
+      *reinterpret_cast<u32x2*>(Cs + crow0 + i * 16 * CPAD + j * 16) = v;
+    }
   __syncthreads();
-  constexpr int CHUNKS = BN / 8;  // 16-byte chunks per output row
   for (int idx = tid; idx < BM * CHUNKS; idx += 256) {
     const int row = idx / CHUNKS, ch = idx - row * CHUNKS;
     const int m = m0 + row;
     if (m < a.M) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(Cs + row * CPAD + ch * 8);
-      *reinterpret_cast<u32x4*>(a.out + (size_t)m * a.Cout + n0 + ch * 8) = v;
+      const size_t pix = dense ? (size_t)m : out_index(m);
+      *reinterpret_cast<u32x4*>(a.out + pix * a.Cout + n0 + ch * 8) = v;
+    }
+  }
+  if (a.stat_sum) {
+    // per-channel sum / sum of squares of the ROUNDED outputs of this tile (rows >= M are exact zeros)
+    constexpr int PARTS = 256 / BN;           // threads per column
+    constexpr int RPP = BM / PARTS;           // rows per thread
+    const int col = tid % BN, part = tid / BN;
+    float s = 0.f, q = 0.f;
+    for (int r = part * RPP; r < (part + 1) * RPP; ++r) {
+      const float v = bfbits(Cs[r * CPAD + col]);
+      s += v; q += v * v;
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem + BM * CPAD * 2);   // behind the C tile: 2*256 floats
+    red[tid] = s; red[256 + tid] = q;
+    __syncthreads();
+    if (tid < BN) {
+      double ds = 0.0, dq = 0.0;
+#pragma unroll
+      for (int p = 0; p < PARTS; ++p) { ds += (double)red[p * BN + tid]; dq += (double)red[256 + p * BN + tid]; }
+      const size_t slot = (size_t)(blockIdx.x % a.stat_slots) * a.Cout + n0 + tid;
+      atomicAdd(a.stat_sum + slot, ds);
+      atomicAdd(a.stat_sumsq + slot, dq);
     }
   }
 }
@@ -185,31 +293,77 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, unsigned short* 
   }
 }
 
+template <int BM, int BN, int WM, int WN, bool DB>
+int launch_conv(const ConvArgs& a, hipStream_t s) {
+  constexpr int STAGE = (BM + BN) * BK * 2;
+  constexpr int CBYTES = BM * (BN + 8) * 2 + 2 * 256 * 4;
+  constexpr int MAIN = (DB ? 2 : 1) * STAGE;
+  constexpr int LDS = MAIN > CBYTES ? MAIN : CBYTES;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, DB>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return ISIC_ERR_LAUNCH;
+    attr_done = true;
+  }
+  dim3 grid(ceil_div(a.M, BM), a.Cout / BN);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, DB>), grid, dim3(256), LDS, s, a);
+  return ISIC_OK;
+}
+
+int g_conv_variant = 0;   // developer knob (isic_debug_set_conv_variant): 0 = single LDS buffer, 1 = double
+
 }  // namespace
 
 extern "C" {
 
 int isic_conv2d_igemm_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int Hin, int Win, int Cin,
-                           int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad, void* stream) {
+                           int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad,
+                           const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots, void* stream) {
   ISIC_CHECK_ARG(in && w && out);
   ISIC_CHECK_ARG(N > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && Kh > 0 && Kw > 0 && up > 0);
-  ISIC_CHECK_ARG(down == 1 || down == 2 || down == 4);
+  ISIC_CHECK_ARG(down == 1 || down == 2);
+  ISIC_CHECK_ARG((stat_sum == nullptr) == (stat_sumsq == nullptr));
+  ISIC_CHECK_ARG(!stat_sum || (stat_slots > 0 && down == 1));
   if (Cin % 64 != 0 || Cout % 64 != 0) return ISIC_ERR_UNSUPPORTED;
-  const int64_t M64 = (int64_t)N * Hout * Wout;
-  if (M64 > 0x7FFFFFFFLL || (int64_t)N * Hin * Win > 0x7FFFFFFFLL) return ISIC_ERR_UNSUPPORTED;
+  if ((int64_t)N * Hout * Wout > 0x7FFFFFFFLL || (int64_t)N * Hin * Win > 0x7FFFFFFFLL) return ISIC_ERR_UNSUPPORTED;
   ConvArgs a;
-  a.in = in; a.w = w; a.out = out;
+  a.in = in; a.w = w; a.out = out; a.addend = addend;
+  a.stat_sum = stat_sum; a.stat_sumsq = stat_sumsq; a.stat_slots = stat_slots > 0 ? stat_slots : 1;
   a.N = N; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
-  a.Kh = Kh; a.Kw = Kw; a.up = up; a.down_shift = down == 1 ? 0 : (down == 2 ? 1 : 2); a.pad = pad;
-  a.M = (int)M64; a.ctiles = Cin / 64; a.Ktiles = Kh * Kw * a.ctiles;
-  if (Cout % 128 != 0) {
-    dim3 grid(ceil_div(a.M, 256), Cout / 64);
-    hipLaunchKernelGGL((conv_igemm_kernel<256, 64, 4, 1>), grid, dim3(256), 0, as_stream(stream), a);
-  } else {
-    dim3 grid(ceil_div(a.M, 128), Cout / 128);
-    hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, as_stream(stream), a);
-  }
+  a.Kh = Kh; a.Kw = Kw; a.up = up; a.down_shift = down == 1 ? 0 : 1; a.pad = pad;
+  a.ctiles = Cin / 64;
+  hipStream_t s = as_stream(stream);
+  // parity classes of the output grid (1 class for down == 1)
+  for (int ph = 0; ph < down; ++ph)
+    for (int pw = 0; pw < down; ++pw) {
+      a.ostep = down; a.oh0 = ph; a.ow0 = pw;
+      a.Hs = (Hout - ph + down - 1) / down; a.Ws = (Wout - pw + down - 1) / down;
+      if (a.Hs <= 0 || a.Ws <= 0) continue;
+      a.kstep = down;
+      // first tap with (o*up + k - pad) divisible by `down` (up == 1 when down > 1)
+      a.kh0 = down == 1 ? 0 : (((pad - ph * up) % down) + down) % down;
+      a.kw0 = down == 1 ? 0 : (((pad - pw * up) % down) + down) % down;
+      a.nkh = a.kh0 < Kh ? (Kh - a.kh0 + down - 1) / down : 0;
+      a.nkw = a.kw0 < Kw ? (Kw - a.kw0 + down - 1) / down : 0;
+      a.M = N * a.Hs * a.Ws;
+      if (a.M >= (1 << 24) || a.Hs * a.Ws >= (1 << 16)) return ISIC_ERR_UNSUPPORTED;   // fastdiv40 domain
+      a.magic_hw = ((1ULL << 40) / (unsigned long long)(a.Hs * a.Ws)) + 1;
+      a.magic_w = ((1ULL << 40) / (unsigned long long)a.Ws) + 1;
+      a.Ktiles = a.nkh * a.nkw * a.ctiles;
+      // a class without any tap still has to write (addend or zeros): Ktiles == 0 is handled by the kernel
+      if (a.nkh > 16 || a.nkw > 16) return ISIC_ERR_UNSUPPORTED;   // per-row tap validity lives in 2 x 16+ bits
+      int rc;
+      if (Cout % 128 != 0) rc = g_conv_variant ? launch_conv<256, 64, 4, 1, true>(a, s) : launch_conv<256, 64, 4, 1, false>(a, s);
+      else rc = g_conv_variant ? launch_conv<128, 128, 2, 2, true>(a, s) : launch_conv<128, 128, 2, 2, false>(a, s);
+      if (rc != ISIC_OK) return rc;
+    }
   return isic_launch_status();
+}
+
+int isic_debug_set_conv_variant(int v) {
+  g_conv_variant = v;
+  return ISIC_OK;
 }
 
 int isic_conv_weight_prep_bf16(const float* w_krsc, uint16_t* w_fwd, uint16_t* w_dgrad, int O, int I, int Kh, int Kw,

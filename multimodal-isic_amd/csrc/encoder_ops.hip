@@ -63,16 +63,18 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const unsigned short* __r
   block_reduce_to_global<2>(acc, C, dst);
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ sum, const double* __restrict__ sumsq, int64_t rows,
-                                   int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+__global__ void bn_finalize_kernel(const double* __restrict__ sum, const double* __restrict__ sumsq, int nslots,
+                                   int64_t rows, int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ scale, float* __restrict__ shift,
                                    float* __restrict__ mean_o, float* __restrict__ rstd_o,
                                    float* __restrict__ running_mean, float* __restrict__ running_var) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double n = (double)rows;
-  const double mean = sum[c] / n;
-  double var = sumsq[c] / n - mean * mean;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nslots; ++k) { s1 += sum[(size_t)k * C + c]; s2 += sumsq[(size_t)k * C + c]; }
+  const double mean = s1 / n;
+  double var = s2 / n - mean * mean;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   const float sc = gamma[c] * rstd;
@@ -102,15 +104,18 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
                                                         const float* __restrict__ shift,
                                                         const unsigned short* __restrict__ residual,
                                                         unsigned short* __restrict__ y, int64_t nvec, int C, int relu) {
-  const int cgs = C >> 3;
+  // the grid stride (gridDim.x * 256) is a multiple of C/8, so a thread always sees the same 8 channels
+  const int cg = threadIdx.x % (C >> 3);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = scale[cg * 8 + j]; sh[j] = shift[cg * 8 + j]; }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-    const int cg = (int)(i % cgs);
     float f[8], rsd[8];
     unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), f);
     if (residual) unpack8(*reinterpret_cast<const u32x4*>(residual + i * 8), rsd);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float v = f[j] * scale[cg * 8 + j] + shift[cg * 8 + j];
+      float v = f[j] * sc[j] + sh[j];
       if (residual) v += rsd[j];
       if (relu) v = fmaxf(v, 0.f);
       f[j] = v;
@@ -124,17 +129,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned short
                                                              const unsigned short* __restrict__ y,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, int64_t rows, int C,
-                                                             int relu, double* __restrict__ dgamma,
+                                                             int relu, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift,
+                                                             double* __restrict__ dgamma,
                                                              double* __restrict__ dbeta) {
   const int tid = threadIdx.x, cgs = C >> 3, cg = tid % cgs, rl = tid / cgs, rls = 256 / cgs;
-  float acc[2][8], mu[8], rs[8];
+  float acc[2][8], mu[8], rs[8], sc[8], sh[8];
+  const bool from_x = relu && scale != nullptr;   // ReLU mask recomputed from x: no read of y
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; mu[j] = mean[cg * 8 + j]; rs[j] = rstd[cg * 8 + j]; }
+  for (int j = 0; j < 8; ++j) {
+    acc[0][j] = 0.f; acc[1][j] = 0.f; mu[j] = mean[cg * 8 + j]; rs[j] = rstd[cg * 8 + j];
+    sc[j] = from_x ? scale[cg * 8 + j] : 0.f; sh[j] = from_x ? shift[cg * 8 + j] : 0.f;
+  }
   for (int64_t r = (int64_t)blockIdx.x * rls + rl; r < rows; r += (int64_t)gridDim.x * rls) {
     float g[8], xv[8], yv[8];
     unpack8(*reinterpret_cast<const u32x4*>(dy + r * C + cg * 8), g);
     unpack8(*reinterpret_cast<const u32x4*>(x + r * C + cg * 8), xv);
-    if (relu) unpack8(*reinterpret_cast<const u32x4*>(y + r * C + cg * 8), yv);
+    if (from_x) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) yv[j] = xv[j] * sc[j] + sh[j];
+    } else if (relu) unpack8(*reinterpret_cast<const u32x4*>(y + r * C + cg * 8), yv);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float dz = (relu && !(yv[j] > 0.f)) ? 0.f : g[j];
@@ -150,9 +164,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x, const unsigned short* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
     const double* __restrict__ dgamma, const double* __restrict__ dbeta, int64_t rows, int C, int relu,
+    const float* __restrict__ scale, const float* __restrict__ shift,
     unsigned short* __restrict__ dx, unsigned short* __restrict__ d_residual, float* __restrict__ dgamma_f32,
     float* __restrict__ dbeta_f32) {
   const int cgs = C >> 3;
+  const bool from_x = relu && scale != nullptr;
   const int64_t nvec = rows * cgs;
   const float inv_rows = 1.f / (float)rows;
   if (blockIdx.x == 0 && dgamma_f32) {
@@ -161,19 +177,32 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
       dbeta_f32[c] += (float)dbeta[c];
     }
   }
+  // per-thread channel constants (grid stride is a multiple of C/8): dx = k1*dz - k2 - xh*k3
+  const int cg = threadIdx.x % cgs;
+  float mu[8], rs[8], k1[8], k2[8], k3[8], sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg * 8 + j;
+    mu[j] = mean[c]; rs[j] = rstd[c];
+    k1[j] = gamma[c] * rs[j];
+    k2[j] = (float)dbeta[c] * inv_rows;
+    k3[j] = (float)dgamma[c] * inv_rows;
+    sc[j] = from_x ? scale[c] : 0.f; sh[j] = from_x ? shift[c] : 0.f;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-    const int cg = (int)(i % cgs);
     float g[8], xv[8], yv[8], o[8];
     unpack8(*reinterpret_cast<const u32x4*>(dy + i * 8), g);
     unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), xv);
-    if (relu) unpack8(*reinterpret_cast<const u32x4*>(y + i * 8), yv);
+    if (from_x) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) yv[j] = xv[j] * sc[j] + sh[j];
+    } else if (relu) unpack8(*reinterpret_cast<const u32x4*>(y + i * 8), yv);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int c = cg * 8 + j;
       const float dz = (relu && !(yv[j] > 0.f)) ? 0.f : g[j];
       g[j] = dz;
-      const float xh = (xv[j] - mean[c]) * rstd[c];
-      o[j] = gamma[c] * rstd[c] * (dz - (float)dbeta[c] * inv_rows - xh * ((float)dgamma[c] * inv_rows));
+      const float xh = (xv[j] - mu[j]) * rs[j];
+      o[j] = k1[j] * (dz - k2[j] - xh * k3[j]);
     }
     *reinterpret_cast<u32x4*>(dx + i * 8) = pack8(o);
     if (d_residual) *reinterpret_cast<u32x4*>(d_residual + i * 8) = pack8(g);
@@ -339,12 +368,13 @@ int isic_bn_stats_bf16(const uint16_t* x, int64_t rows, int C, double* sum, doub
   return isic_launch_status();
 }
 
-int isic_bn_finalize(const double* sum, const double* sumsq, int64_t rows, int C, const float* gamma,
+int isic_bn_finalize(const double* sum, const double* sumsq, int nslots, int64_t rows, int C, const float* gamma,
                      const float* beta, float eps, float momentum, float* scale, float* shift, float* mean,
                      float* rstd, float* running_mean, float* running_var, void* stream) {
-  ISIC_CHECK_ARG(sum && sumsq && gamma && beta && scale && shift && mean && rstd && rows > 0 && C > 0);
+  ISIC_CHECK_ARG(sum && sumsq && gamma && beta && scale && shift && mean && rstd && rows > 0 && C > 0 && nslots > 0);
   ISIC_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, as_stream(stream), sum, sumsq, rows, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, as_stream(stream), sum, sumsq, nslots,
+                     rows, C,
                      gamma, beta, eps, momentum, scale, shift, mean, rstd, running_mean, running_var);
   return isic_launch_status();
 }
@@ -367,27 +397,29 @@ int isic_bn_apply_bf16(const uint16_t* x, const float* scale, const float* shift
 }
 
 int isic_bn_bwd_reduce_bf16(const uint16_t* dy, const uint16_t* x, const uint16_t* y, const float* mean,
-                            const float* rstd, int64_t rows, int C, int relu, double* dgamma, double* dbeta,
-                            void* stream) {
+                            const float* rstd, int64_t rows, int C, int relu, const float* scale,
+                            const float* shift, double* dgamma, double* dbeta, void* stream) {
   ISIC_CHECK_ARG(dy && x && mean && rstd && dgamma && dbeta && rows > 0 && C > 0);
-  ISIC_CHECK_ARG(!relu || y);
+  ISIC_CHECK_ARG((scale == nullptr) == (shift == nullptr));
+  ISIC_CHECK_ARG(!relu || y || scale);
   if (!bn_c_ok(C)) return ISIC_ERR_UNSUPPORTED;
   const int rls = 256 / (C / 8);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid_for(rows, rls * 8, 2048)), dim3(256), 0, as_stream(stream), dy, x,
-                     y, mean, rstd, rows, C, relu, dgamma, dbeta);
+                     y, mean, rstd, rows, C, relu, scale, shift, dgamma, dbeta);
   return isic_launch_status();
 }
 
 int isic_bn_bwd_apply_bf16(const uint16_t* dy, const uint16_t* x, const uint16_t* y, const float* mean,
                            const float* rstd, const float* gamma, const double* dgamma, const double* dbeta,
-                           int64_t rows, int C, int relu, uint16_t* dx, uint16_t* d_residual, float* dgamma_f32,
-                           float* dbeta_f32, void* stream) {
+                           int64_t rows, int C, int relu, const float* scale, const float* shift, uint16_t* dx,
+                           uint16_t* d_residual, float* dgamma_f32, float* dbeta_f32, void* stream) {
   ISIC_CHECK_ARG(dy && x && mean && rstd && gamma && dgamma && dbeta && dx && rows > 0 && C > 0 && C % 8 == 0);
-  ISIC_CHECK_ARG(!relu || y);
+  ISIC_CHECK_ARG((scale == nullptr) == (shift == nullptr));
+  ISIC_CHECK_ARG(!relu || y || scale);
   ISIC_CHECK_ARG((dgamma_f32 == nullptr) == (dbeta_f32 == nullptr));
   const int64_t nvec = rows * (C / 8);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), dy, x, y, mean,
-                     rstd, gamma, dgamma, dbeta, rows, C, relu, dx, d_residual, dgamma_f32, dbeta_f32);
+                     rstd, gamma, dgamma, dbeta, rows, C, relu, scale, shift, dx, d_residual, dgamma_f32, dbeta_f32);
   return isic_launch_status();
 }
 

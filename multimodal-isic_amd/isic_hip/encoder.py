@@ -18,6 +18,7 @@ from .lib import IsicHipError, call
 
 LAYERS = ((64, 1), (128, 2), (256, 2), (512, 2))
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+STAT_SLOTS = 32          # partial rows of the conv-epilogue BatchNorm statistics (spreads the fp64 atomics)
 _BF16 = torch.bfloat16
 
 
@@ -77,6 +78,7 @@ class ResNet18Encoder(nn.Module):
                 self.blocks.append((pre, ds))
                 inp = planes
         self._wcache = {}      # conv name -> (w_fwd bf16, w_dgrad bf16)
+        self._wgrad_ws = None
         self.grad_ready_hook = None   # callable(list_of_param_names) fired as gradients complete (DDP overlap)
 
     # parameters are registered under dotted torchvision names via nested holder modules
@@ -135,23 +137,31 @@ class ResNet18Encoder(nn.Module):
         return self._wcache[name]
 
     # ------------------------------------------------------------------ primitive launches
-    def _conv_fwd(self, x, name):
+    def _conv_fwd(self, x, name, with_stats=True):
+        """conv forward; in training also returns the fused per-channel (sum, sumsq) partials of the
+        rounded output (BatchNorm statistics without a second pass over it)."""
         sp = self.specs[name]
         N, H, W, C = x.shape
         Ho = (H + 2 * sp.pad - sp.k) // sp.stride + 1
         Wo = (W + 2 * sp.pad - sp.k) // sp.stride + 1
         wf, _ = self._weights(name, False)
         out = _empty((N, Ho, Wo, sp.cout), x)
-        call("isic_conv2d_igemm_bf16", x, wf, out, N, H, W, C, Ho, Wo, sp.cout, sp.k, sp.k, sp.stride, 1, sp.pad)
-        return out
+        acc = None
+        if with_stats and self.training:
+            acc = torch.zeros(2, STAT_SLOTS, sp.cout, device=x.device, dtype=torch.float64)
+        call("isic_conv2d_igemm_bf16", x, wf, out, N, H, W, C, Ho, Wo, sp.cout, sp.k, sp.k, sp.stride, 1, sp.pad, None,
+             acc[0] if acc is not None else None, acc[1] if acc is not None else None, STAT_SLOTS)
+        return out, acc
 
-    def _conv_dgrad(self, dy, name, in_shape):
+    def _conv_dgrad(self, dy, name, in_shape, addend=None):
+        """d_x = dgrad(dy) (+ addend, joined in fp32 inside the kernel's epilogue)."""
         sp = self.specs[name]
         N, H, W, C = in_shape
         _, Ho, Wo, Co = dy.shape
         _, wd = self._weights(name, True)
         dx = _empty(in_shape, dy)
-        call("isic_conv2d_igemm_bf16", dy, wd, dx, N, Ho, Wo, Co, H, W, C, sp.k, sp.k, 1, sp.stride, sp.k - 1 - sp.pad)
+        call("isic_conv2d_igemm_bf16", dy, wd, dx, N, Ho, Wo, Co, H, W, C, sp.k, sp.k, 1, sp.stride, sp.k - 1 - sp.pad,
+             addend, None, None, 0)
         return dx
 
     def _grad_buffer(self, p):
@@ -167,13 +177,14 @@ class ResNet18Encoder(nn.Module):
             raise IsicHipError(f"{name}.weight.grad must be channels_last ([O][Kh][Kw][I] memory)")
         N, H, W, C = x.shape
         _, Ho, Wo, Co = dy.shape
-        chunk = max(1, ((1 << 24) - 1) // (Ho * Wo))
-        for n0 in range(0, N, chunk):
-            n1 = min(N, n0 + chunk)
-            call("isic_conv2d_wgrad_bf16", x[n0:n1], dy[n0:n1], g, n1 - n0, H, W, C, Ho, Wo, Co, sp.k, sp.k,
-                 sp.stride, sp.pad)
+        nbytes = N * Ho * Wo * 8 + 64
+        ws = self._wgrad_ws
+        if ws is None or ws.numel() < nbytes or ws.device != x.device:
+            ws = self._wgrad_ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+        call("isic_conv2d_wgrad_bf16", x, dy, g, N, H, W, C, Ho, Wo, Co, sp.k, sp.k, sp.stride, sp.pad, ws, ws.numel())
 
-    def _bn_fwd(self, c, name, relu, residual=None):
+    def _bn_fwd(self, c, name, relu, residual=None, acc=None):
+        """Returns (y, (mean, rstd, scale, shift)).  ``acc`` = fused statistics from the producing conv."""
         N, H, W, C = c.shape
         rows = N * H * W
         gamma, beta = self._get(name + ".weight"), self._get(name + ".bias")
@@ -182,29 +193,37 @@ class ResNet18Encoder(nn.Module):
         shift = torch.empty(C, device=dev, dtype=torch.float32)
         mean = rstd = None
         if self.training:
-            acc = torch.zeros(2, C, device=dev, dtype=torch.float64)
+            slots = STAT_SLOTS
+            if acc is None:
+                slots = 1
+                acc = torch.zeros(2, 1, C, device=dev, dtype=torch.float64)
+                call("isic_bn_stats_bf16", c, rows, C, acc[0], acc[1])
             mean = torch.empty(C, device=dev, dtype=torch.float32)
             rstd = torch.empty(C, device=dev, dtype=torch.float32)
-            call("isic_bn_stats_bf16", c, rows, C, acc[0], acc[1])
-            call("isic_bn_finalize", acc[0], acc[1], rows, C, gamma.data, beta.data, BN_EPS, BN_MOMENTUM, scale, shift,
-                 mean, rstd, self._get(name + ".running_mean"), self._get(name + ".running_var"))
+            call("isic_bn_finalize", acc[0], acc[1], slots, rows, C, gamma.data, beta.data, BN_EPS, BN_MOMENTUM, scale,
+                 shift, mean, rstd, self._get(name + ".running_mean"), self._get(name + ".running_var"))
         else:
             call("isic_bn_eval_affine", gamma.data, beta.data, self._get(name + ".running_mean"),
                  self._get(name + ".running_var"), BN_EPS, C, scale, shift)
         y = _empty(c.shape, c)
         call("isic_bn_apply_bf16", c, scale, shift, residual, y, rows, C, int(relu))
-        return y, mean, rstd
+        return y, (mean, rstd, scale, shift)
 
-    def _bn_bwd(self, dy, c, y, mean, rstd, name, relu, want_residual):
+    def _bn_bwd(self, dy, c, y, st, name, relu, want_residual, mask_from_x=False):
+        """BatchNorm(+ReLU) backward.  ``mask_from_x``: no residual was added, so the ReLU mask is
+        recomputed from c*scale+shift and y is not read."""
+        mean, rstd, scale, shift = st
         N, H, W, C = c.shape
         rows = N * H * W
         gamma, beta = self._get(name + ".weight"), self._get(name + ".bias")
         acc = torch.zeros(2, C, device=c.device, dtype=torch.float64)
-        call("isic_bn_bwd_reduce_bf16", dy, c, y, mean, rstd, rows, C, int(relu), acc[0], acc[1])
+        sc, sh = (scale, shift) if (mask_from_x and relu) else (None, None)
+        yy = None if (mask_from_x or not relu) else y
+        call("isic_bn_bwd_reduce_bf16", dy, c, yy, mean, rstd, rows, C, int(relu), sc, sh, acc[0], acc[1])
         dx = _empty(c.shape, c)
         dres = _empty(c.shape, c) if want_residual else None
-        call("isic_bn_bwd_apply_bf16", dy, c, y, mean, rstd, gamma.data, acc[0], acc[1], rows, C, int(relu), dx, dres,
-             self._grad_buffer(gamma), self._grad_buffer(beta))
+        call("isic_bn_bwd_apply_bf16", dy, c, yy, mean, rstd, gamma.data, acc[0], acc[1], rows, C, int(relu), sc, sh, dx,
+             dres, self._grad_buffer(gamma), self._grad_buffer(beta))
         return dx, dres
 
     def _fire(self, names):
@@ -236,24 +255,24 @@ class ResNet18Encoder(nn.Module):
         ws, _ = self._weights("conv1", False)
         c = _empty((N, Ho, Wo, 64), x0)
         call("isic_conv_stem_fwd_bf16", x0, ws, c, N, H, W, Ho, Wo)
-        y, m, r = self._bn_fwd(c, "bn1", True)
+        y, st0 = self._bn_fwd(c, "bn1", True)
         Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
         p = _empty((N, Hp, Wp, 64), y)
         am = torch.empty((N, Hp, Wp, 64), device=y.device, dtype=torch.uint8) if save else None
         call("isic_maxpool3x3s2_fwd_bf16", y, p, am, N, Ho, Wo, 64, Hp, Wp)
-        tape = {"x0": x0, "stem": (c, y, m, r, am, (N, Ho, Wo, 64)), "blocks": []} if save else None
+        tape = {"x0": x0, "stem": (c, y, st0, am, (N, Ho, Wo, 64)), "blocks": []} if save else None
         x = p
         for pre, ds in self.blocks:
-            idn, cd, md, rd = x, None, None, None
+            idn, cd, std = x, None, None
             if ds:
-                cd = self._conv_fwd(x, f"{pre}.downsample.0")
-                idn, md, rd = self._bn_fwd(cd, f"{pre}.downsample.1", False)
-            c1 = self._conv_fwd(x, f"{pre}.conv1")
-            a1, m1, r1 = self._bn_fwd(c1, f"{pre}.bn1", True)
-            c2 = self._conv_fwd(a1, f"{pre}.conv2")
-            out, m2, r2 = self._bn_fwd(c2, f"{pre}.bn2", True, residual=idn)
+                cd, accd = self._conv_fwd(x, f"{pre}.downsample.0")
+                idn, std = self._bn_fwd(cd, f"{pre}.downsample.1", False, acc=accd)
+            c1, acc1 = self._conv_fwd(x, f"{pre}.conv1")
+            a1, st1 = self._bn_fwd(c1, f"{pre}.bn1", True, acc=acc1)
+            c2, acc2 = self._conv_fwd(a1, f"{pre}.conv2")
+            out, st2 = self._bn_fwd(c2, f"{pre}.bn2", True, residual=idn, acc=acc2)
             if save:
-                tape["blocks"].append((x, c1, a1, m1, r1, c2, out, m2, r2, cd, md, rd))
+                tape["blocks"].append((x, c1, a1, st1, c2, out, st2, cd, std))
             x = out
         N, Hf, Wf, Cf = x.shape
         feat = torch.empty((N, Cf), device=x.device, dtype=torch.float32)
@@ -279,34 +298,33 @@ class ResNet18Encoder(nn.Module):
         g = torch.empty((N, Hf, Wf, Cf), device=dfeat.device, dtype=_BF16)
         call("isic_avgpool_bwd_bf16", dfeat.float().contiguous(), g, N, Hf * Wf, Cf)
         for (pre, ds), saved in zip(reversed(self.blocks), reversed(tape["blocks"])):
-            x, c1, a1, m1, r1, c2, out, m2, r2, cd, md, rd = saved
-            dc2, dres = self._bn_bwd(g, c2, out, m2, r2, f"{pre}.bn2", True, True)
+            x, c1, a1, st1, c2, out, st2, cd, std = saved
+            dc2, dres = self._bn_bwd(g, c2, out, st2, f"{pre}.bn2", True, True)
             self._conv_wgrad(a1, dc2, f"{pre}.conv2")
             da1 = self._conv_dgrad(dc2, f"{pre}.conv2", tuple(a1.shape))
             del dc2
-            dc1, _ = self._bn_bwd(da1, c1, a1, m1, r1, f"{pre}.bn1", True, False)
+            dc1, _ = self._bn_bwd(da1, c1, a1, st1, f"{pre}.bn1", True, False, mask_from_x=True)
             del da1
             self._conv_wgrad(x, dc1, f"{pre}.conv1")
-            dx = self._conv_dgrad(dc1, f"{pre}.conv1", tuple(x.shape))
-            del dc1
             names = [f"{pre}.conv2.weight", f"{pre}.bn2.weight", f"{pre}.bn2.bias", f"{pre}.conv1.weight",
                      f"{pre}.bn1.weight", f"{pre}.bn1.bias"]
             if ds:
-                dcd, _ = self._bn_bwd(dres, cd, None, md, rd, f"{pre}.downsample.1", False, False)
+                dcd, _ = self._bn_bwd(dres, cd, None, std, f"{pre}.downsample.1", False, False)
                 self._conv_wgrad(x, dcd, f"{pre}.downsample.0")
                 dx2 = self._conv_dgrad(dcd, f"{pre}.downsample.0", tuple(x.shape))
-                call("isic_add_bf16", dx, dx2, dx.numel())
+                dx = self._conv_dgrad(dc1, f"{pre}.conv1", tuple(x.shape), addend=dx2)
                 names += [f"{pre}.downsample.0.weight", f"{pre}.downsample.1.weight", f"{pre}.downsample.1.bias"]
             else:
-                call("isic_add_bf16", dx, dres, dx.numel())
+                dx = self._conv_dgrad(dc1, f"{pre}.conv1", tuple(x.shape), addend=dres)   # + identity gradient
+            del dc1
             g = dx
             self._fire(names)
-        c, y, m, r, am, yshape = tape["stem"]
+        c, y, st0, am, yshape = tape["stem"]
         N, Ho, Wo, _ = yshape
         _, Hp, Wp, _ = g.shape
         dy = _empty(yshape, g)
         call("isic_maxpool3x3s2_bwd_bf16", am, g, dy, N, Ho, Wo, 64, Hp, Wp)
-        dc, _ = self._bn_bwd(dy, c, y, m, r, "bn1", True, False)
+        dc, _ = self._bn_bwd(dy, c, y, st0, "bn1", True, False, mask_from_x=True)
         x0 = tape["x0"]
         p = self._get("conv1.weight")
         gw = self._grad_buffer(p)

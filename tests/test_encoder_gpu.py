@@ -73,8 +73,14 @@ def test_conv_forward(case):
     wd = torch.empty_like(wf)
     call("isic_conv_weight_prep_bf16", krsc(w), wf, wd, Co, Ci, k, k)
     out = torch.empty(N, Ho, Wo, Co, device=DEV, dtype=BF)
-    call("isic_conv2d_igemm_bf16", nhwc(x), wf, out, N, H, W, Ci, Ho, Wo, Co, k, k, s, 1, p)
+    slots = 32
+    acc = torch.zeros(2, slots, Co, device=DEV, dtype=torch.float64)
+    call("isic_conv2d_igemm_bf16", nhwc(x), wf, out, N, H, W, Ci, Ho, Wo, Co, k, k, s, 1, p, None, acc[0], acc[1], slots)
     bf16_close(from_nhwc(out), ref, f"conv fwd {case}")
+    # fused BatchNorm statistics == statistics of the rounded output (fp32 partials per tile: 1e-5)
+    o = out.float().reshape(-1, Co).double()
+    assert_close(acc[0].sum(0), o.sum(0), rtol=1e-5, atol=1e-4, what="fused sum")
+    assert_close(acc[1].sum(0), (o * o).sum(0), rtol=1e-5, atol=1e-4, what="fused sumsq")
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
@@ -93,10 +99,16 @@ def test_conv_dgrad_and_wgrad(case):
     call("isic_conv_weight_prep_bf16", krsc(w.detach()), wf, wd, Co, Ci, k, k)
     dyd = nhwc(dy)
     dx = torch.empty(N, H, W, Ci, device=DEV, dtype=BF)
-    call("isic_conv2d_igemm_bf16", dyd, wd, dx, N, Ho, Wo, Co, H, W, Ci, k, k, 1, s, k - 1 - p)
+    call("isic_conv2d_igemm_bf16", dyd, wd, dx, N, Ho, Wo, Co, H, W, Ci, k, k, 1, s, k - 1 - p, None, None, None, 0)
     bf16_close(from_nhwc(dx), x.grad, f"conv dgrad {case}")
+    # fused residual-gradient join: one rounding of (dgrad + addend)
+    add = rb(torch.randn(N, Ci, H, W, generator=torch.Generator().manual_seed(4)))
+    dx2 = torch.empty(N, H, W, Ci, device=DEV, dtype=BF)
+    call("isic_conv2d_igemm_bf16", dyd, wd, dx2, N, Ho, Wo, Co, H, W, Ci, k, k, 1, s, k - 1 - p, nhwc(add), None, None, 0)
+    bf16_close(from_nhwc(dx2), x.grad + add, f"conv dgrad+addend {case}")
     dw = torch.zeros(Co, Ci, k, k, device=DEV).contiguous(memory_format=torch.channels_last)
-    call("isic_conv2d_wgrad_bf16", nhwc(x.detach()), dyd, dw, N, H, W, Ci, Ho, Wo, Co, k, k, s, p)
+    ws = torch.empty(N * Ho * Wo * 8 + 64, device=DEV, dtype=torch.uint8)
+    call("isic_conv2d_wgrad_bf16", nhwc(x.detach()), dyd, dw, N, H, W, Ci, Ho, Wo, Co, k, k, s, p, ws, ws.numel())
     # fp32 result of exactly-representable operands: summation order only
     assert_close(dw.cpu(), w.grad, rtol=2e-4, atol=1e-5, what=f"conv wgrad {case}")
 
@@ -147,7 +159,7 @@ def test_batchnorm_forward_backward(C, relu, res):
     scale, shift, mean, rstd = (torch.empty(C, device=DEV) for _ in range(4))
     rmd, rvd = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
     call("isic_bn_stats_bf16", xd, rows, C, acc[0], acc[1])
-    call("isic_bn_finalize", acc[0], acc[1], rows, C, gamma.detach().to(DEV), beta.detach().to(DEV), 1e-5, 0.1, scale,
+    call("isic_bn_finalize", acc[0], acc[1], 1, rows, C, gamma.detach().to(DEV), beta.detach().to(DEV), 1e-5, 0.1, scale,
          shift, mean, rstd, rmd, rvd)
     assert_close(rmd.cpu(), rm, rtol=1e-5, atol=1e-6, what="running_mean")
     assert_close(rvd.cpu(), rv, rtol=1e-5, atol=1e-6, what="running_var")
@@ -156,12 +168,15 @@ def test_batchnorm_forward_backward(C, relu, res):
     bf16_close(from_nhwc(yd), y.detach(), "bn fwd")
     acc2 = torch.zeros(2, C, device=DEV, dtype=torch.float64)
     dyd = nhwc(dy)
-    call("isic_bn_bwd_reduce_bf16", dyd, xd, yd, mean, rstd, rows, C, relu, acc2[0], acc2[1])
+    # without a residual the ReLU mask is recomputed from x (y is not even passed)
+    from_x = bool(relu and not res)
+    sc, sh, yy = (scale, shift, None) if from_x else (None, None, yd)
+    call("isic_bn_bwd_reduce_bf16", dyd, xd, yy, mean, rstd, rows, C, relu, sc, sh, acc2[0], acc2[1])
     dx = torch.empty_like(xd)
     dres = torch.empty_like(xd) if res else None
     dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
-    call("isic_bn_bwd_apply_bf16", dyd, xd, yd, mean, rstd, gamma.detach().to(DEV), acc2[0], acc2[1], rows, C, relu,
-         dx, dres, dg, db)
+    call("isic_bn_bwd_apply_bf16", dyd, xd, yy, mean, rstd, gamma.detach().to(DEV), acc2[0], acc2[1], rows, C, relu,
+         sc, sh, dx, dres, dg, db)
     # the ReLU mask comes from the bf16-rounded output: elements within one rounding of 0 may flip
     assert_close(dg.cpu(), gamma.grad, rtol=2e-2, atol=2e-2, what="dgamma")
     assert_close(db.cpu(), beta.grad, rtol=2e-2, atol=2e-2, what="dbeta")
@@ -222,7 +237,7 @@ def _encoder_pair(seed=0, layers=resnet.LAYERS):
 def _stage_report(enc, tape, taps):
     rep = {}
     names = ["stem"] + [pre for pre, _ in enc.blocks]
-    outs = [tape["stem"][1]] + [b[6] for b in tape["blocks"]]
+    outs = [tape["stem"][1]] + [b[5] for b in tape["blocks"]]
     for n, o in zip(names, outs):
         r = taps[n]
         d = from_nhwc(o)
