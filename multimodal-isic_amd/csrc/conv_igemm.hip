@@ -25,11 +25,15 @@
 //
 // Structure: 256 threads = 4 waves; block tile BM x BN (256x64 as 4x1 waves for Cout = 64,
 // 128x128 as 2x2 waves otherwise), each wave a 64x64 sub-tile = 4x4 MFMA tiles (64 accumulator
-// VGPRs); BK = 64 = one (kh,kw) tap x 64 channels.  Global -> registers -> LDS staging into TWO LDS
-// buffers: the next K-tile's global loads are issued before the current tile's MFMAs and written to
-// the other buffer after them, one barrier per K-tile.  LDS rows are 128 B with a 16-byte-chunk XOR
-// swizzle (chunk ^= row & 7) so the ds_read_b128 fragment reads are conflict-free; the epilogue
-// transposes through LDS so every global store is a full 16-byte-per-lane row segment.
+// VGPRs); BK = 64 = one (kh,kw) tap x 64 channels.  Staging is LDS-DMA (global_load_lds, 16 B per
+// lane, no staging VGPRs, no ds_write) into two LDS stages: tile k+1 streams in while tile k is
+// multiplied, one barrier per K-tile, two blocks per CU.  LDS rows are 128 B with a 16-byte-chunk XOR
+// swizzle applied on the SOURCE side (the DMA writes lane-linearly) so the ds_read_b128 fragment
+// reads are conflict-free; out-of-image taps are fetched from a zero page.  The epilogue transposes
+// through LDS so every global store is a full 16-byte-per-lane row segment.  (Register-staged and
+// 3-stage variants are kept behind ISIC_CONV_MODE for A/B timing; measured slower.)
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -68,13 +72,21 @@ __device__ __forceinline__ unsigned range_mask(int base, int lo, int hi, int cnt
 
 __device__ __forceinline__ float bfbits(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool DB>
+// zero page for LDS-DMA staging: an out-of-image tap row is fetched from here instead of being zero-filled
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
+
+// MODE 0: one LDS stage, register staging      MODE 1: two LDS stages, register staging
+// MODE 2: two LDS stages, LDS-DMA staging       MODE 3: three LDS stages, LDS-DMA, counted vmcnt
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  constexpr bool DB = (MODE == 1);
+  constexpr bool GLDS = (MODE >= 2);
+  constexpr int NSTAGE = MODE == 3 ? 3 : (MODE == 0 ? 1 : 2);
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   static_assert(BM == WAVES_M * 64 && BN == WAVES_N * 64, "64x64 per wave");
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int CPAD = BN + 8;  // epilogue row stride (elements)
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // (DB ? 2 : 1)*STAGE, >= C tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NSTAGE*STAGE, >= C tile
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -86,7 +98,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   // element offset at (dh, dw) = (0, 0) plus one validity bit per tap row / tap column; inside the K loop a
   // row costs two bit tests, one add and one select.
   constexpr int AROWS = BM / 32, BROWS = BN / 32;
-  const int sr = tid >> 3, sc = tid & 7;
+  const int sr = tid >> 3;
+  const int sc = GLDS ? ((tid & 7) ^ (sr & 7)) : (tid & 7);   // global 16-byte chunk this thread fetches
   const int ds_ = a.down_shift;
   // per-tap uniform offsets: dh(ti) = (oh0*up + kh - pad) >> ds  (exact for the taps of this parity class)
   const int dh0 = (a.oh0 * a.up + a.kh0 - a.pad) >> ds_, dw0 = (a.ow0 * a.up + a.kw0 - a.pad) >> ds_;
@@ -166,7 +179,44 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
   };
-  if (DB) {
+  if (GLDS) {
+    // LDS-DMA staging (global_load_lds, 16 B per lane): a wave-instruction fills 8 consecutive 128-byte rows
+    // lane-linearly, so lane (r8 = lane>>3, p = lane&7) supplies global chunk p ^ r8 of row 8*g + r8 -- the same
+    // swizzled image the register path builds.  No staging VGPRs, no ds_write; NSTAGE-1 tiles in flight.
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    const unsigned char* zp = g_zero_page + (tid & 7) * 16;
+    auto issue = [&](int kt, unsigned char* stage) {
+      const int tap = kt / a.ctiles, c0 = (kt - tap * a.ctiles) * BK;
+      const int ti = tap / a.nkw, tj = tap - ti * a.nkw;
+      const int toff = ((dh0 + dstep * ti) * a.Win + (dw0 + dstep * tj)) * a.Cin + c0;          // uniform
+      const int koff = ((a.kh0 + a.kstep * ti) * a.Kw + (a.kw0 + a.kstep * tj)) * a.Cin + c0;     // uniform
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) {
+        const bool ok = ((a_vh[i] >> ti) & (a_vw[i] >> tj)) & 1u;
+        const void* src = ok ? (const void*)(a.in + (a_off[i] + toff)) : (const void*)zp;
+        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(stage + (wave * 8 + 32 * i) * 128), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < BROWS; ++i)
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(wrow_ptr[i] + koff),
+                                         (lds_ptr)(stage + A_BYTES + (wave * 8 + 32 * i) * 128), 16, 0, 0);
+    };
+    constexpr int LPT = AROWS + BROWS;        // LDS-DMA instructions per wave per K-tile
+#pragma unroll
+    for (int s_ = 0; s_ < NSTAGE - 1; ++s_)
+      if (s_ < a.Ktiles) issue(s_, smem + s_ * STAGE);
+    for (int kt = 0; kt < a.Ktiles; ++kt) {
+      // tile kt landed when at most the (NSTAGE-2) younger tiles' loads are still outstanding
+      if (NSTAGE == 3 && kt + 1 < a.Ktiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();           // everyone's part landed; everyone is done with stage (kt-1) % NSTAGE
+      if (kt + NSTAGE - 1 < a.Ktiles) issue(kt + NSTAGE - 1, smem + ((kt + NSTAGE - 1) % NSTAGE) * STAGE);
+      unsigned char* As = smem + (kt % NSTAGE) * STAGE;
+      compute(As, As + A_BYTES);
+    }
+    __syncthreads();
+  } else if (DB) {
     // variant 1: two LDS stages, one register set, one barrier per K-tile
     if (a.Ktiles > 0) {   // a parity class of a strided data gradient can have no tap at all
       gload(0, ra0, rb0);
@@ -293,25 +343,43 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, unsigned short* 
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool DB>
+template <int BM, int BN, int WM, int WN, int MODE>
 int launch_conv(const ConvArgs& a, hipStream_t s) {
   constexpr int STAGE = (BM + BN) * BK * 2;
   constexpr int CBYTES = BM * (BN + 8) * 2 + 2 * 256 * 4;
-  constexpr int MAIN = (DB ? 2 : 1) * STAGE;
+  constexpr int MAIN = (MODE == 3 ? 3 : (MODE == 0 ? 1 : 2)) * STAGE;
   constexpr int LDS = MAIN > CBYTES ? MAIN : CBYTES;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, DB>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, MODE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return ISIC_ERR_LAUNCH;
     attr_done = true;
   }
   dim3 grid(ceil_div(a.M, BM), a.Cout / BN);
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, DB>), grid, dim3(256), LDS, s, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MODE>), grid, dim3(256), LDS, s, a);
   return ISIC_OK;
 }
 
-int g_conv_variant = 0;   // developer knob (isic_debug_set_conv_variant): 0 = single LDS buffer, 1 = double
+template <int BM, int BN, int WM, int WN>
+int launch_conv_mode(int mode, const ConvArgs& a, hipStream_t s) {
+  switch (mode) {
+    case 1: return launch_conv<BM, BN, WM, WN, 1>(a, s);
+    case 2: return launch_conv<BM, BN, WM, WN, 2>(a, s);
+    case 3: return launch_conv<BM, BN, WM, WN, 3>(a, s);
+    default: return launch_conv<BM, BN, WM, WN, 0>(a, s);
+  }
+}
+
+int g_conv_variant = -1;  // staging MODE of conv_igemm_kernel; -1 = not chosen yet (env ISIC_CONV_MODE or default)
+constexpr int kDefaultConvMode = 2;   // LDS-DMA, two stages: fastest measured (tools/kernel_bench.py)
+inline int conv_mode() {
+  if (g_conv_variant < 0) {
+    const char* e = getenv("ISIC_CONV_MODE");
+    g_conv_variant = (e && e[0] >= '0' && e[0] <= '3') ? (e[0] - '0') : kDefaultConvMode;
+  }
+  return g_conv_variant;
+}
 
 }  // namespace
 
@@ -354,8 +422,8 @@ int isic_conv2d_igemm_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out,
       // a class without any tap still has to write (addend or zeros): Ktiles == 0 is handled by the kernel
       if (a.nkh > 16 || a.nkw > 16) return ISIC_ERR_UNSUPPORTED;   // per-row tap validity lives in 2 x 16+ bits
       int rc;
-      if (Cout % 128 != 0) rc = g_conv_variant ? launch_conv<256, 64, 4, 1, true>(a, s) : launch_conv<256, 64, 4, 1, false>(a, s);
-      else rc = g_conv_variant ? launch_conv<128, 128, 2, 2, true>(a, s) : launch_conv<128, 128, 2, 2, false>(a, s);
+      if (Cout % 128 != 0) rc = launch_conv_mode<256, 64, 4, 1>(conv_mode(), a, s);
+      else rc = launch_conv_mode<128, 128, 2, 2>(conv_mode(), a, s);
       if (rc != ISIC_OK) return rc;
     }
   return isic_launch_status();
