@@ -7,8 +7,9 @@
 // dimension: the MFMA fragments (8 consecutive k per lane for one row/column) are produced by
 // staging [pixels][channels] tiles in LDS untransposed (coalesced 16-byte global loads) and
 // reading them back with ds_read_b64_tr_b16, gfx950's transposing LDS read (4 pixels x 16
-// channels per 16-lane group, delivered channel-per-lane).  Rows are padded by 32 bytes so the 8
-// pixel rows a 32-lane half touches land in disjoint banks.
+// channels per 16-lane group, delivered channel-per-lane).  Staging is LDS-DMA (global_load_lds,
+// two stages, no staging VGPRs); the 32-byte granules of a row are XOR-swizzled on the source side so
+// the 8 pixel rows a 32-lane half touches land in disjoint banks.
 //
 // Pixel -> source-address decoding is hoisted out of the hot loop into a per-call table
 // (8 bytes per output pixel: element offset of tap (0,0) + packed (ho, wo)), built by a tiny
@@ -20,8 +21,9 @@
 //   <KSPLIT=true>   64 co x  64 ci per block (the 64-channel layers): all four waves own the whole
 //                   64x64 tile (4x4 MFMA tiles each, same LDS-read : MFMA ratio as above) and split
 //                   the 128-pixel K-tile four ways.
-// The pixel range is additionally split over blockIdx.y; partial sums are accumulated with fp32
-// atomics into the caller's gradient buffer.
+// The pixel range is additionally split over blockIdx.y; a block's partial tile is transposed through
+// LDS (and, with KSPLIT, summed over its four waves there) and added to the caller's gradient as whole
+// 256-byte rows, one fp32 atomic wave-instruction per row.
 #include "common.h"
 
 namespace {
@@ -29,7 +31,7 @@ namespace {
 struct WgradArgs {
   const unsigned short* x;
   const unsigned short* dy;
-  float* dw;
+  float* dw;           // [Cout][Kh][Kw][Cin] fp32, accumulated into
   const int2* tab;     // [M] : .x = ((n*Hin + ho*s - p)*Win + wo*s - p)*Cin, .y = ho << 16 | wo
   int N, Hin, Win, Cin, Hout, Wout, Cout, Kh, Kw, stride, pad;
   int M;               // N*Hout*Wout
@@ -51,17 +53,30 @@ __global__ void wgrad_table_kernel(int2* __restrict__ tab, int M, int Hout, int 
   tab[m] = e;
 }
 
+// One LDS-DMA instruction from inline asm: 64 lanes x 16 B from per-lane global addresses to the wave-uniform LDS
+// byte address `lds_dst` (+ lane*16).  Issued from asm so that hipcc neither counts it in vmcnt nor fences the
+// following ds_read_tr with a vmcnt(0) drain (it does for the builtin form in this kernel); completion is
+// tracked by the loop's own s_waitcnt.  M0 (the DMA's LDS base) is saved and restored inside the statement.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// zero page: rows past the end of the pixel range and out-of-image taps are fetched from here
+__device__ __attribute__((aligned(256))) unsigned char g_wgrad_zero_page[256];
+
 template <bool KSPLIT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int BC = KSPLIT ? 64 : 128;              // channels per block (co and ci)
   constexpr int BKP = KSPLIT ? 128 : 64;             // pixels per K-tile
-  constexpr int SROW = BC * 2 + 32;                  // LDS row stride in bytes
-  constexpr int CH = BC / 8;                         // 16-byte chunks per row
-  constexpr int PER_T = BKP * CH / 256;              // chunk loads per thread per operand (4)
-  constexpr int RSTEP = 256 / CH;                    // rows between a thread's successive chunks
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BKP * SROW];
-  unsigned char* As = smem;
-  unsigned char* Bs = smem + BKP * SROW;
+  constexpr int ROWB = BC * 2;                       // LDS row bytes (no padding: XOR swizzle on 32-byte granules)
+  constexpr int OPB = BKP * ROWB;                    // bytes per operand tile (16 KB)
+  constexpr int STAGE = 2 * OPB;
+  constexpr int RPI = 1024 / ROWB;                   // rows per LDS-DMA wave-instruction (4 or 8)
+  constexpr int PER_T = 4;                           // DMA instructions per wave per operand per K-tile
+  constexpr int RSTEP = 4 * RPI;                     // rows between a lane's successive instructions (16 or 32)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = KSPLIT ? 0 : (wave >> 1), wn = KSPLIT ? 0 : (wave & 1);
@@ -76,42 +91,58 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   int kt_end = kt_begin + a.ktiles_per_split;
   if (kt_end > a.ktiles) kt_end = a.ktiles;
 
-  const int srow = tid / CH, sch = tid - srow * CH;          // this thread's first row / its chunk
-  const int tapoff = (kh * a.Win + kw) * a.Cin + ci0 + sch * 8;
+  // LDS-DMA lane mapping: a wave-instruction writes 1 KB lane-linearly = RPI whole rows.  Lane l lands in row
+  // (l / slots) at 16-byte slot (l % slots); the 32-byte granule q' = slot >> 1 of row r holds global granule
+  // q' ^ swz(r).  A transposing read's 32-lane half touches pixel rows {b, b+1, b+2, b+3, b+8, .., b+11} (one
+  // 32-byte granule each), so swz must separate exactly those 8 rows over the 256-byte bank row:
+  //   256-byte rows: swz(r) = (r & 3) | ((r >> 3) & 1) << 2           (8 granules per row)
+  //   128-byte rows: swz(r) = ((r >> 1) & 1) | ((r >> 3) & 1) << 1    (4 granules per row, 2 rows per bank row)
+  // swz is the same for all of a lane's rows (they differ by multiples of 16 / 32).
+  constexpr int SLOTS = ROWB / 16;
+  const int lrow = wave * RPI + lane / SLOTS;                 // this lane's first row in the tile
+  const int slot = lane % SLOTS;
+  const int swz = KSPLIT ? (((lrow >> 1) & 1) | (((lrow >> 3) & 1) << 1)) : ((lrow & 3) | (((lrow >> 3) & 1) << 2));
+  const int gchunk = 2 * ((slot >> 1) ^ swz) + (slot & 1);    // global 16-byte chunk of the row this lane fetches
+  const int tapoff = (kh * a.Win + kw) * a.Cin + ci0 + gchunk * 8;
   const int hlo = a.pad - kh, wlo = a.pad - kw;              // valid iff hlo <= ho*s < Hin + hlo
-  u32x4 ra[PER_T], rb[PER_T];
-  int2 ent[PER_T];                       // table entries of the NEXT tile to be loaded (prefetched a tile early,
-                                         // so the x loads never wait behind a dependent table load)
+  const unsigned char* zp = g_wgrad_zero_page + (lane & 7) * 16;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr;
+  // Table entries of the NEXT tile to be issued, prefetched one tile early.  These are ordinary register loads
+  // living next to LDS-DMA traffic: if hipcc sees them it drains vmcnt(0) around them (and before the first
+  // ds_read of the tile), which serialises DMA and MFMA.  They are therefore issued from inline asm (invisible
+  // to the compiler's wait-count bookkeeping) and retired by the loop's own s_waitcnt vmcnt(0), whose asm
+  // statement names them "+v" so that no use can be scheduled above it.
+  unsigned long long ent[PER_T];
   auto tload = [&](int kt) {
-    const int mbase = kt * BKP + srow;
+    const int mbase = kt * BKP + lrow;
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+      int m = mbase + RSTEP * i;
+      m = m < a.M ? m : a.M - 1;                              // always a valid address; validity is re-derived at issue
+      const int2* p = a.tab + m;
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(ent[i]) : "v"(p) : "memory");
+    }
+  };
+  auto twait = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ent[0]), "+v"(ent[1]), "+v"(ent[2]), "+v"(ent[3])::"memory");
+  };
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);     // provably wave-uniform for the "s" operand
+  const unsigned lds_base = (unsigned)(size_t)(lds_ptr)smem;  // LDS byte address of the staging area
+  auto issue = [&](int kt, unsigned stage) {                   // stage = LDS byte address of the target stage
+    const int mbase = kt * BKP + lrow;
 #pragma unroll
     for (int i = 0; i < PER_T; ++i) {
       const int m = mbase + RSTEP * i;
-      ent[i] = m < a.M ? a.tab[m] : make_int2(0, 0);
-    }
-  };
-  auto gload = [&](int kt) {
-    const int mbase = kt * BKP + srow;
-#pragma unroll
-    for (int i = 0; i < PER_T; ++i) {
-      const int m = mbase + RSTEP * i;
-      u32x4 va = {0u, 0u, 0u, 0u}, vb = {0u, 0u, 0u, 0u};
-      if (m < a.M) {
-        va = *reinterpret_cast<const u32x4*>(a.dy + (size_t)m * a.Cout + co0 + sch * 8);
-        const int2 e = ent[i];
-        const int hs = (e.y >> 16) * a.stride, ws = (e.y & 0xFFFF) * a.stride;
-        if (hs >= hlo && hs < a.Hin + hlo && ws >= wlo && ws < a.Win + wlo)
-          vb = *reinterpret_cast<const u32x4*>(a.x + (e.x + tapoff));
-      }
-      ra[i] = va; rb[i] = vb;
-    }
-  };
-  auto lstore = [&]() {
-#pragma unroll
-    for (int i = 0; i < PER_T; ++i) {
-      const int r = srow + RSTEP * i;
-      *reinterpret_cast<u32x4*>(As + r * SROW + sch * 16) = ra[i];
-      *reinterpret_cast<u32x4*>(Bs + r * SROW + sch * 16) = rb[i];
+      const int ex = (int)(unsigned)ent[i], ey = (int)(unsigned)(ent[i] >> 32);
+      const bool inr = m < a.M;
+      const int hs = (ey >> 16) * a.stride, ws = (ey & 0xFFFF) * a.stride;
+      const bool okx = inr && hs >= hlo && hs < a.Hin + hlo && ws >= wlo && ws < a.Win + wlo;
+      const void* sa = inr ? (const void*)(a.dy + (size_t)m * a.Cout + co0 + gchunk * 8) : (const void*)zp;
+      const void* sb = okx ? (const void*)(a.x + (ex + tapoff)) : (const void*)zp;
+      const unsigned dst = stage + (unsigned)((wave_u * RPI + RSTEP * i) * ROWB);
+      glds16(sa, dst);
+      glds16(sb, dst + OPB);
     }
   };
 
@@ -124,32 +155,41 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const int fg = lane >> 4, fi = lane & 15, fq = fi >> 2, fp = fi & 3;
   typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
   constexpr int KSTEPS = KSPLIT ? 1 : 2;               // 32-pixel MFMA steps per wave per K-tile
-  if (kt_begin < kt_end) { tload(kt_begin); gload(kt_begin); }
-  if (kt_begin + 1 < kt_end) tload(kt_begin + 1);
+  // swizzle terms of the two 4-row blocks a lane addresses: rows (8*fg + fq) and (8*fg + fq + 4) (+ multiples of 32)
+  const int r0_ = 8 * fg + fq, r1_ = r0_ + 4;
+  const int sw0 = KSPLIT ? (((r0_ >> 1) & 1) | (((r0_ >> 3) & 1) << 1)) : ((r0_ & 3) | (((r0_ >> 3) & 1) << 2));
+  const int sw1 = KSPLIT ? (((r1_ >> 1) & 1) | (((r1_ >> 3) & 1) << 1)) : ((r1_ & 3) | (((r1_ >> 3) & 1) << 2));
+  if (kt_begin < kt_end) {
+    tload(kt_begin);
+    twait();
+    issue(kt_begin, lds_base);
+    if (kt_begin + 1 < kt_end) tload(kt_begin + 1);
+  }
   for (int kt = kt_begin; kt < kt_end; ++kt) {
-    __syncthreads();
-    lstore();
-    __syncthreads();
-    if (kt + 1 < kt_end) gload(kt + 1);
+    twait();                                           // tile kt (and the table entries of kt+1) landed
+    __builtin_amdgcn_s_barrier();                      // ... for every wave; stage (kt+1)&1 is free again
+    if (kt + 1 < kt_end) issue(kt + 1, lds_base + (unsigned)((((kt - kt_begin) + 1) & 1) * STAGE));
     if (kt + 2 < kt_end) tload(kt + 2);
+    const unsigned char* As = smem + ((kt - kt_begin) & 1) * STAGE;
+    const unsigned char* Bs = As + OPB;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       const int prow = (KSPLIT ? wave * 32 : ks * 32) + 8 * fg + fq;   // first pixel row this lane addresses
       bf16x8 af[4], bfr[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const unsigned char* p0 = As + prow * SROW + ((wm * 4 + i) * 16 + 4 * fp) * 2;
+        const int cb = wm * 4 + i;
         s16x8_t t;
-        t.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
-        t.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + 4 * SROW));
+        t.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(As + prow * ROWB + ((cb ^ sw0) << 5) + fp * 8));
+        t.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(As + (prow + 4) * ROWB + ((cb ^ sw1) << 5) + fp * 8));
         af[i] = __builtin_bit_cast(bf16x8, t);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const unsigned char* p0 = Bs + prow * SROW + ((wn * 4 + j) * 16 + 4 * fp) * 2;
+        const int cb = wn * 4 + j;
         s16x8_t t;
-        t.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
-        t.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + 4 * SROW));
+        t.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Bs + prow * ROWB + ((cb ^ sw0) << 5) + fp * 8));
+        t.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Bs + (prow + 4) * ROWB + ((cb ^ sw1) << 5) + fp * 8));
         bfr[j] = __builtin_bit_cast(bf16x8, t);
       }
 #pragma unroll
@@ -160,26 +200,67 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
   }
 
-  // accumulate: row = co, col = ci  ->  dw[co][kh][kw][ci]
-  const size_t row_stride = (size_t)a.Kh * a.Kw * a.Cin;
+  // ---- epilogue: every wave parks its 64x64 fp32 partial tile in LDS ([co][ci], 16 KB per wave: exactly the
+  // staging area), then whole 256-byte rows go out as ONE atomic wave-instruction each (the shape the memory-
+  // side atomic units run at full rate).  With KSPLIT the four waves hold partials of the SAME tile: they are
+  // summed here, so a block issues 64 row-atomics instead of 4 x 64 x 4 scattered ones.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                   // staging buffers are dead from here on
+  float* Ct = reinterpret_cast<float*>(smem) + wave * (64 * 64);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = co0 + (wm * 4 + i) * 16 + fg * 4 + r;
-        const int ci = ci0 + (wn * 4 + j) * 16 + fi;
-        atomicAdd(a.dw + (size_t)co * row_stride + (size_t)tap * a.Cin + ci, acc[i][j][r]);
-      }
+      for (int r = 0; r < 4; ++r) Ct[(i * 16 + fg * 4 + r) * 64 + j * 16 + fi] = acc[i][j][r];
+  __syncthreads();
+  const size_t row_stride = (size_t)a.Kh * a.Kw * a.Cin;
+  const float* C0 = reinterpret_cast<const float*>(smem);
+  if (KSPLIT) {
+    for (int rr = 0; rr < 16; ++rr) {
+      const int row = wave * 16 + rr;
+      const float v = (C0[row * 64 + lane] + C0[4096 + row * 64 + lane]) + (C0[8192 + row * 64 + lane] + C0[12288 + row * 64 + lane]);
+      atomicAdd(a.dw + (size_t)(co0 + row) * row_stride + (size_t)tap * a.Cin + ci0 + lane, v);
+    }
+  } else {
+    for (int row = 0; row < 64; ++row)
+      atomicAdd(a.dw + (size_t)(co0 + wm * 64 + row) * row_stride + (size_t)tap * a.Cin + ci0 + wn * 64 + lane,
+                Ct[row * 64 + lane]);
+  }
+}
+
+struct WgradPlan {
+  bool big;
+  int tiles, splits, ktiles, ktiles_per_split;
+  size_t table_bytes;
+};
+
+WgradPlan wgrad_plan(int N, int Cin, int Hout, int Wout, int Cout, int Kh, int Kw) {
+  WgradPlan p;
+  const int M = N * Hout * Wout;
+  p.big = (Cin % 128 == 0) && (Cout % 128 == 0);
+  const int tc = p.big ? 128 : 64, bkp = p.big ? 64 : 128;
+  p.ktiles = ceil_div(M, bkp);
+  p.tiles = (Cout / tc) * (Cin / tc) * Kh * Kw;
+  // two blocks per CU are resident (64 KB LDS each): ~2.5 rounds of 512 blocks, each with >= 8 K-tiles
+  int splits = ceil_div(1280, p.tiles);
+  if (splits > ceil_div(p.ktiles, 8)) splits = ceil_div(p.ktiles, 8);
+  if (splits < 1) splits = 1;
+  if (splits > 4096) splits = 4096;
+  p.ktiles_per_split = ceil_div(p.ktiles, splits);
+  p.splits = ceil_div(p.ktiles, p.ktiles_per_split);
+  p.table_bytes = ((size_t)M * sizeof(int2) + 255) / 256 * 256;
+  return p;
 }
 
 }  // namespace
 
 extern "C" {
 
-size_t isic_conv2d_wgrad_workspace_bytes(int N, int Hout, int Wout) {
-  return (size_t)N * Hout * Wout * sizeof(int2) + 64;
+size_t isic_conv2d_wgrad_workspace_bytes(int N, int Cin, int Hout, int Wout, int Cout, int Kh, int Kw) {
+  if (N <= 0 || Cin <= 0 || Hout <= 0 || Wout <= 0 || Cout <= 0 || Kh <= 0 || Kw <= 0) return 0;
+  const WgradPlan p = wgrad_plan(N, Cin, Hout, Wout, Cout, Kh, Kw);
+  return p.table_bytes + 256;
 }
 
 int isic_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dw, int N, int Hin, int Win, int Cin,
@@ -187,33 +268,26 @@ int isic_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dw, int
                            size_t workspace_bytes, void* stream) {
   ISIC_CHECK_ARG(x && dy && dw && workspace);
   ISIC_CHECK_ARG(N > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && Kh > 0 && Kw > 0 && stride > 0 && pad >= 0);
+  ISIC_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0);
   if (Cin % 64 != 0 || Cout % 64 != 0) return ISIC_ERR_UNSUPPORTED;
   const int64_t M64 = (int64_t)N * Hout * Wout;
   if (M64 > 0x7FFFFFFFLL / 2 || (int64_t)N * Hin * Win * Cin > 0x7FFFFFFFLL || Hout >= 32768 || Wout >= 32768)
     return ISIC_ERR_UNSUPPORTED;   // 32-bit element offsets / 16-bit packed coordinates
-  if (workspace_bytes < isic_conv2d_wgrad_workspace_bytes(N, Hout, Wout)) return ISIC_ERR_WORKSPACE;
+  const WgradPlan p = wgrad_plan(N, Cin, Hout, Wout, Cout, Kh, Kw);
+  if (workspace_bytes < p.table_bytes) return ISIC_ERR_WORKSPACE;
   WgradArgs a;
   a.x = x; a.dy = dy; a.dw = dw; a.tab = reinterpret_cast<const int2*>(workspace);
   a.N = N; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
   a.Kh = Kh; a.Kw = Kw; a.stride = stride; a.pad = pad;
   a.M = (int)M64;
+  a.ktiles = p.ktiles; a.ktiles_per_split = p.ktiles_per_split;
+  const int tc = p.big ? 128 : 64;
+  a.co_tiles = Cout / tc; a.ci_tiles = Cin / tc;
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(wgrad_table_kernel, dim3(ceil_div(a.M, 256)), dim3(256), 0, s, reinterpret_cast<int2*>(workspace),
                      a.M, Hout, Wout, Hin, Win, Cin, stride, pad);
-  const bool big = (Cin % 128 == 0) && (Cout % 128 == 0);
-  const int tc = big ? 128 : 64, bkp = big ? 64 : 128;
-  a.ktiles = ceil_div(a.M, bkp);
-  a.co_tiles = Cout / tc; a.ci_tiles = Cin / tc;
-  const int tiles = a.co_tiles * a.ci_tiles * Kh * Kw;
-  // enough K-splits for ~4 blocks per CU, each with at least 8 K-tiles
-  int splits = ceil_div(1024, tiles);
-  if (splits > ceil_div(a.ktiles, 8)) splits = ceil_div(a.ktiles, 8);
-  if (splits < 1) splits = 1;
-  if (splits > 65535) splits = 65535;
-  a.ktiles_per_split = ceil_div(a.ktiles, splits);
-  splits = ceil_div(a.ktiles, a.ktiles_per_split);
-  dim3 grid(tiles, splits);
-  if (big) hipLaunchKernelGGL((conv_wgrad_kernel<false>), grid, dim3(256), 0, s, a);
+  dim3 grid(p.tiles, p.splits);
+  if (p.big) hipLaunchKernelGGL((conv_wgrad_kernel<false>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((conv_wgrad_kernel<true>), grid, dim3(256), 0, s, a);
   return isic_launch_status();
 }

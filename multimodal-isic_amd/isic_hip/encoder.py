@@ -177,10 +177,10 @@ class ResNet18Encoder(nn.Module):
             raise IsicHipError(f"{name}.weight.grad must be channels_last ([O][Kh][Kw][I] memory)")
         N, H, W, C = x.shape
         _, Ho, Wo, Co = dy.shape
-        nbytes = N * Ho * Wo * 8 + 64
+        nbytes = call("isic_conv2d_wgrad_workspace_bytes", N, C, Ho, Wo, Co, sp.k, sp.k)
         ws = self._wgrad_ws
         if ws is None or ws.numel() < nbytes or ws.device != x.device:
-            ws = self._wgrad_ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+            ws = self._wgrad_ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)   # caching allocator: 512-B aligned
         call("isic_conv2d_wgrad_bf16", x, dy, g, N, H, W, C, Ho, Wo, Co, sp.k, sp.k, sp.stride, sp.pad, ws, ws.numel())
 
     def _bn_fwd(self, c, name, relu, residual=None, acc=None):

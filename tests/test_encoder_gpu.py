@@ -107,7 +107,7 @@ def test_conv_dgrad_and_wgrad(case):
     call("isic_conv2d_igemm_bf16", dyd, wd, dx2, N, Ho, Wo, Co, H, W, Ci, k, k, 1, s, k - 1 - p, nhwc(add), None, None, 0)
     bf16_close(from_nhwc(dx2), x.grad + add, f"conv dgrad+addend {case}")
     dw = torch.zeros(Co, Ci, k, k, device=DEV).contiguous(memory_format=torch.channels_last)
-    ws = torch.empty(N * Ho * Wo * 8 + 64, device=DEV, dtype=torch.uint8)
+    ws = torch.empty(call("isic_conv2d_wgrad_workspace_bytes", N, Ci, Ho, Wo, Co, k, k), device=DEV, dtype=torch.uint8)
     call("isic_conv2d_wgrad_bf16", nhwc(x.detach()), dyd, dw, N, H, W, Ci, Ho, Wo, Co, k, k, s, p, ws, ws.numel())
     # fp32 result of exactly-representable operands: summation order only
     assert_close(dw.cpu(), w.grad, rtol=2e-4, atol=1e-5, what=f"conv wgrad {case}")

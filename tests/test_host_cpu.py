@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     assert L.fn["isic_gcn_csr_workspace_bytes"](10, 20) == (6 * 10 + 2 * 30 + 64) * 4
     assert L.fn["isic_gemm_f32"](0, 0, -1, 4, 4, None, 4, None, 4, None, 4, None, 0, 0.0, None) == -1
     assert L.fn["isic_conv2d_igemm_bf16"](1, 1, 1, 1, 8, 8, 48, 8, 8, 64, 3, 3, 1, 1, 1, None, None, None, 0, None) == -2   # Cin % 64
-    assert L.fn["isic_conv2d_wgrad_workspace_bytes"](2, 7, 7) == 2 * 49 * 8 + 64
+    assert L.fn["isic_conv2d_wgrad_workspace_bytes"](2, 64, 7, 7, 64, 3, 3) >= 2 * 49 * 8
 
 
 def test_header_prototypes_parse():

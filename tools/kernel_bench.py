@@ -38,7 +38,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=512)
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=2)
     ap.add_argument("--only", default="", help="substring filter on the conv shape names; also skips the extra kernels")
     a = ap.parse_args()
     call("isic_debug_set_conv_variant", a.variant)
@@ -62,7 +62,7 @@ def main():
         gf = 2.0 * N * ho * ho * co * k * k * ci / 1e9
         tf = timeit(lambda: call("isic_conv2d_igemm_bf16", x, wf, out, N, h, h, ci, ho, ho, co, k, k, s, 1, p, None, acc[0], acc[1], 32), a.iters)
         td = timeit(lambda: call("isic_conv2d_igemm_bf16", dy, wd, dx, N, ho, ho, co, h, h, ci, k, k, 1, s, k - 1 - p, None, None, None, 0), a.iters)
-        wsb = torch.empty(N * ho * ho * 8 + 64, device=DEV, dtype=torch.uint8)
+        wsb = torch.empty(call("isic_conv2d_wgrad_workspace_bytes", N, ci, ho, ho, co, k, k), device=DEV, dtype=torch.uint8)
         tw = timeit(lambda: call("isic_conv2d_wgrad_bf16", x, dy, dw, N, h, h, ci, ho, ho, co, k, k, s, p, wsb, wsb.numel()), a.iters)
         print(f"{name:28s} {gf:8.1f} | {tf:8.3f} {gf / tf:7.0f} | {td:8.3f} {gf / td:7.0f} | {tw:8.3f} {gf / tw:7.0f}   x{cnt}")
         tot["fwd"] += tf * cnt; tot["dgrad"] += td * cnt; tot["wgrad"] += tw * cnt
