@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--bags-per-step", type=int, default=8, help="bags per optimizer step PER GPU")
+    ap.add_argument("--bags-per-step", type=int, default=16, help="bags per optimizer step PER GPU")
     ap.add_argument("--patches", type=int, default=64)
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--radiomics-dim", type=int, default=128)
@@ -150,7 +150,8 @@ def main():
         opt.step(grad_scale=1.0 / world)
         return loss
 
-    for i in range(args.warmup):
+    # two untimed settle steps (allocator growth, kernel attribute setup) precede the W warm-up steps
+    for i in range(2 + args.warmup):
         step(i)
     if world > 1:
         dist.barrier()
@@ -158,7 +159,7 @@ def main():
     timer.active = True
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = step(args.warmup + i)
+        loss = step(2 + args.warmup + i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -193,7 +194,7 @@ def main():
             "roofline": {
                 "bound": "mfma", "kernel": "conv_igemm_kernel (isic_conv2d_igemm_bf16: forward + data-gradient)",
                 "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(B, K, S),
                 "launches": n_launch, "avg_launch_ms": conv_ms / max(n_launch, 1),
                 "algorithmic_gflop_per_launch": conv_fl / max(n_launch, 1) / 1e9,
                 "share_of_step_time": conv_ms * 1e-3 / elapsed,
@@ -205,6 +206,20 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(B, K, S):
+    """HBM bytes per conv_igemm launch from the rocprofv3 PMC passes of THIS command, collected offline
+    (counters need their own runs: `tools/collect_traffic.sh`) and committed as profiles/r01_pmc_traffic.json;
+    None when no collection matches the workload."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+        if d.get("bags_per_step") == B and d.get("patches") == K and d.get("image_size") == S:
+            return d["conv_igemm_hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(model, K, S, R, C, budget_s):
