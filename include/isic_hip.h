@@ -113,6 +113,12 @@ int isic_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
                        const float* rstd, float* dx, float* dgamma, float* dbeta, int M, int N, int relu,
                        uint32_t drop_threshold, float drop_scale, uint64_t seed, uint64_t stream_id, void* stream);
 
+/* y = x / max(||x||_2, eps) per row and its backward: F.normalize of
+ * SAGEConv(normalize=True) (05_train_gnns.py:87-88). */
+int isic_l2normalize_fwd(const float* x, float* y, float* norm, int M, int N, float eps, void* stream);
+int isic_l2normalize_bwd(const float* dy, const float* y, const float* norm, float* dx, int M, int N, float eps,
+                         void* stream);
+
 /* ------------------------------------------------------------------ loss
  * Per-sample cross entropy, mean over B, and its gradient scaled by
  * grad_scale/B.  mode 0: inputs are logits (01_train_mil_teacher.py:143,244);
@@ -155,11 +161,14 @@ int isic_knn_graph(const float* x, const int64_t* offsets, int G, int D, int k, 
  * Outputs: rowptr[n_nodes+1], col[E+n_nodes] (source ids; edges keep their
  * edge_index order within a row, self loop last), val[E+n_nodes]; and the
  * transposed structure (CSR by source) rowptr_t/col_t/val_t for the backward
- * pass.  workspace: isic_gcn_csr_workspace_bytes(n_nodes, E) bytes. */
+ * pass.  workspace: isic_gcn_csr_workspace_bytes(n_nodes, E) bytes.
+ * mode 0 = the GCN normalisation above; mode 1 = plain sum aggregation (val = w, no
+ * self loops: GINConv, 05_train_gnns.py:89-93); mode 2 = mean aggregation (val =
+ * w / in-degree: SAGEConv(aggr='mean'), 05_train_gnns.py:87-88). */
 size_t isic_gcn_csr_workspace_bytes(int64_t n_nodes, int64_t E);
 int isic_gcn_csr_build(const int64_t* src, const int64_t* dst, const float* edge_weight, int64_t E, int64_t n_nodes,
-                       int32_t* rowptr, int32_t* col, float* val, int32_t* rowptr_t, int32_t* col_t, float* val_t,
-                       void* workspace, size_t workspace_bytes, void* stream);
+                       int mode, int32_t* rowptr, int32_t* col, float* val, int32_t* rowptr_t, int32_t* col_t,
+                       float* val_t, void* workspace, size_t workspace_bytes, void* stream);
 /* out[i,:] = alpha * sum_{e in row i} val[e] * x[col[e],:] (+ bias) (+ addend_scale*addend[i,:])
  * -- the neighbour gather / segmented sum of GCNConv.propagate
  * (05_train_gnns.py:184-185); GCN2Conv's (1-alpha) A^ x + alpha x_0 with addend.

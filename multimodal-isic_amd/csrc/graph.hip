@@ -117,27 +117,30 @@ __global__ void csr_init_kernel(int* __restrict__ cnt, float* __restrict__ loopw
   for (; i < n; i += stride) loopw[i] = 1.0f;
 }
 
+// mode 0 (GCN): self loops are dropped here and re-added (one per node) by the row kernels
+// mode 1/2 (sum / mean aggregation, SAGE / GIN): every edge is kept as it is, no loop is added
 __global__ void csr_count_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
                                  const float* __restrict__ w, int64_t E, int64_t n, int* __restrict__ cnt_in,
-                                 int* __restrict__ cnt_out, float* __restrict__ loopw) {
+                                 int* __restrict__ cnt_out, float* __restrict__ loopw, int mode) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; e < E; e += stride) {
     const int64_t s = src[e], d = dst[e];
-    if (s == d) { loopw[s] = w ? w[e] : 1.0f; }
+    if (mode == 0 && s == d) { loopw[s] = w ? w[e] : 1.0f; }
     else { atomicAdd(&cnt_in[d], 1); atomicAdd(&cnt_out[s], 1); }
   }
 }
 
-// single-block exclusive scan of (cnt[i] + 1) for both directions
+// single-block exclusive scan of (cnt[i] + extra) for both directions (extra = 1 slot for the GCN self loop)
 __global__ __launch_bounds__(1024) void csr_scan_kernel(const int* __restrict__ cnt_in, const int* __restrict__ cnt_out,
-                                                         int64_t n, int* __restrict__ rowptr, int* __restrict__ rowptr_t) {
+                                                         int64_t n, int* __restrict__ rowptr, int* __restrict__ rowptr_t,
+                                                         int extra) {
   __shared__ int part[2][1024];
   const int tid = threadIdx.x;
   const int64_t per = (n + 1023) / 1024;
   const int64_t b = tid * per, e = (b + per < n) ? b + per : n;
   int s0 = 0, s1 = 0;
-  for (int64_t i = b; i < e; ++i) { s0 += cnt_in[i] + 1; s1 += cnt_out[i] + 1; }
+  for (int64_t i = b; i < e; ++i) { s0 += cnt_in[i] + extra; s1 += cnt_out[i] + extra; }
   part[0][tid] = s0; part[1][tid] = s1;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(const int* __restrict__ 
   int r0 = part[0][tid] - s0, r1 = part[1][tid] - s1;   // exclusive prefix of this thread's chunk
   for (int64_t i = b; i < e; ++i) {
     rowptr[i] = r0; rowptr_t[i] = r1;
-    r0 += cnt_in[i] + 1; r1 += cnt_out[i] + 1;
+    r0 += cnt_in[i] + extra; r1 += cnt_out[i] + extra;
   }
   if (tid == 1023) { rowptr[n] = part[0][1023]; rowptr_t[n] = part[1][1023]; }
 }
@@ -159,12 +162,12 @@ __global__ void csr_fill_kernel(const int64_t* __restrict__ src, const int64_t* 
                                 const float* __restrict__ w, int64_t E, const int* __restrict__ rowptr,
                                 const int* __restrict__ rowptr_t, int* __restrict__ fill_in, int* __restrict__ fill_out,
                                 int* __restrict__ col, float* __restrict__ val, int* __restrict__ eid,
-                                int* __restrict__ col_t, float* __restrict__ val_t, int* __restrict__ eid_t) {
+                                int* __restrict__ col_t, float* __restrict__ val_t, int* __restrict__ eid_t, int mode) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; e < E; e += stride) {
     const int64_t s = src[e], d = dst[e];
-    if (s == d) continue;
+    if (mode == 0 && s == d) continue;
     const float wv = w ? w[e] : 1.0f;
     const int p = rowptr[d] + atomicAdd(&fill_in[d], 1);
     col[p] = (int)s; val[p] = wv; eid[p] = (int)e;
@@ -186,31 +189,44 @@ __device__ void sort_row(int* col, float* val, int* eid, int b, int e) {
 __global__ void csr_sort_kernel(const int* __restrict__ rowptr, const int* __restrict__ rowptr_t, int64_t n,
                                 const float* __restrict__ loopw, int* __restrict__ col, float* __restrict__ val,
                                 int* __restrict__ eid, int* __restrict__ col_t, float* __restrict__ val_t,
-                                int* __restrict__ eid_t, float* __restrict__ dis) {
+                                int* __restrict__ eid_t, float* __restrict__ dis, int mode) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  {
-    const int b = rowptr[i], e = rowptr[i + 1] - 1;   // last slot = self loop
-    sort_row(col, val, eid, b, e);
-    col[e] = (int)i; val[e] = loopw[i];
-    float deg = 0.f;
-    for (int p = b; p <= e; ++p) deg += val[p];        // deg[i] = sum of weights INTO i (+ loop)
-    dis[i] = deg > 0.f ? 1.0f / sqrtf(deg) : 0.f;      // deg^-1/2, inf -> 0
-  }
-  {
-    const int b = rowptr_t[i], e = rowptr_t[i + 1] - 1;
-    sort_row(col_t, val_t, eid_t, b, e);
-    col_t[e] = (int)i; val_t[e] = loopw[i];
+  if (mode == 0) {
+    {
+      const int b = rowptr[i], e = rowptr[i + 1] - 1;   // last slot = self loop
+      sort_row(col, val, eid, b, e);
+      col[e] = (int)i; val[e] = loopw[i];
+      float deg = 0.f;
+      for (int p = b; p <= e; ++p) deg += val[p];        // deg[i] = sum of weights INTO i (+ loop)
+      dis[i] = deg > 0.f ? 1.0f / sqrtf(deg) : 0.f;      // deg^-1/2, inf -> 0
+    }
+    {
+      const int b = rowptr_t[i], e = rowptr_t[i + 1] - 1;
+      sort_row(col_t, val_t, eid_t, b, e);
+      col_t[e] = (int)i; val_t[e] = loopw[i];
+    }
+  } else {
+    sort_row(col, val, eid, rowptr[i], rowptr[i + 1]);
+    sort_row(col_t, val_t, eid_t, rowptr_t[i], rowptr_t[i + 1]);
+    const int cnt = rowptr[i + 1] - rowptr[i];            // in-degree (number of incoming edges)
+    dis[i] = (mode == 2 && cnt > 0) ? 1.0f / (float)cnt : (mode == 2 ? 0.f : 1.0f);
   }
 }
 __global__ void csr_norm_kernel(const int* __restrict__ rowptr, const int* __restrict__ rowptr_t, int64_t n,
                                 const float* __restrict__ dis, const int* __restrict__ col, float* __restrict__ val,
-                                const int* __restrict__ col_t, float* __restrict__ val_t) {
+                                const int* __restrict__ col_t, float* __restrict__ val_t, int mode) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  // w^ = dis[src] * w * dis[dst]  (PyG order of operations)
-  for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) val[p] = (dis[col[p]] * val[p]) * dis[i];        // row = dst
-  for (int p = rowptr_t[i]; p < rowptr_t[i + 1]; ++p) val_t[p] = (dis[i] * val_t[p]) * dis[col_t[p]];  // row = src
+  if (mode == 0) {
+    // w^ = dis[src] * w * dis[dst]  (PyG order of operations)
+    for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) val[p] = (dis[col[p]] * val[p]) * dis[i];        // row = dst
+    for (int p = rowptr_t[i]; p < rowptr_t[i + 1]; ++p) val_t[p] = (dis[i] * val_t[p]) * dis[col_t[p]];  // row = src
+  } else {
+    // sum: w ; mean: w / in-degree(dst)   (dis[] holds 1 or 1/in-degree of the DESTINATION)
+    for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) val[p] = val[p] * dis[i];
+    for (int p = rowptr_t[i]; p < rowptr_t[i + 1]; ++p) val_t[p] = val_t[p] * dis[col_t[p]];
+  }
 }
 
 // ================================================================= SpMM
@@ -287,9 +303,10 @@ size_t isic_gcn_csr_workspace_bytes(int64_t n_nodes, int64_t E) {
 }
 
 int isic_gcn_csr_build(const int64_t* src, const int64_t* dst, const float* edge_weight, int64_t E, int64_t n_nodes,
-                       int32_t* rowptr, int32_t* col, float* val, int32_t* rowptr_t, int32_t* col_t, float* val_t,
-                       void* workspace, size_t workspace_bytes, void* stream) {
+                       int mode, int32_t* rowptr, int32_t* col, float* val, int32_t* rowptr_t, int32_t* col_t,
+                       float* val_t, void* workspace, size_t workspace_bytes, void* stream) {
   ISIC_CHECK_ARG(E >= 0 && n_nodes > 0 && rowptr && col && val && rowptr_t && col_t && val_t && workspace);
+  ISIC_CHECK_ARG(mode >= 0 && mode <= 2);
   ISIC_CHECK_ARG(E == 0 || (src && dst));
   if (E + n_nodes > 0x7FFFFFF0LL) return ISIC_ERR_UNSUPPORTED;
   if (workspace_bytes < isic_gcn_csr_workspace_bytes(n_nodes, E)) return ISIC_ERR_WORKSPACE;
@@ -303,15 +320,17 @@ int isic_gcn_csr_build(const int64_t* src, const int64_t* dst, const float* edge
   hipLaunchKernelGGL(csr_init_kernel, dim3(grid_for(4 * n_nodes, 256)), dim3(256), 0, s, cnt, loopw, n_nodes);
   if (E > 0)
     hipLaunchKernelGGL(csr_count_kernel, dim3(grid_for(E, 256)), dim3(256), 0, s, src, dst, edge_weight, E, n_nodes,
-                       cnt_in, cnt_out, loopw);
-  hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, s, cnt_in, cnt_out, n_nodes, rowptr, rowptr_t);
+                       cnt_in, cnt_out, loopw, mode);
+  hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, s, cnt_in, cnt_out, n_nodes, rowptr, rowptr_t,
+                     mode == 0 ? 1 : 0);
   if (E > 0)
     hipLaunchKernelGGL(csr_fill_kernel, dim3(grid_for(E, 256)), dim3(256), 0, s, src, dst, edge_weight, E, rowptr,
-                       rowptr_t, fill_in, fill_out, col, val, eid, col_t, val_t, eid_t);
+                       rowptr_t, fill_in, fill_out, col, val, eid, col_t, val_t, eid_t, mode);
   const int g = (int)((n_nodes + 255) / 256);
   hipLaunchKernelGGL(csr_sort_kernel, dim3(g), dim3(256), 0, s, rowptr, rowptr_t, n_nodes, loopw, col, val, eid, col_t,
-                     val_t, eid_t, dis);
-  hipLaunchKernelGGL(csr_norm_kernel, dim3(g), dim3(256), 0, s, rowptr, rowptr_t, n_nodes, dis, col, val, col_t, val_t);
+                     val_t, eid_t, dis, mode);
+  hipLaunchKernelGGL(csr_norm_kernel, dim3(g), dim3(256), 0, s, rowptr, rowptr_t, n_nodes, dis, col, val, col_t, val_t,
+                     mode);
   return isic_launch_status();
 }
 

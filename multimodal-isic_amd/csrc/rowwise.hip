@@ -94,6 +94,34 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
   }
 }
 
+// y = x / max(||x||_2, eps) per row (F.normalize(p=2, dim=-1) of SAGEConv(normalize=True)), wave per row
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          float* __restrict__ norm, int M, int N, float eps) {
+  const int lane = threadIdx.x & 63;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+    float s = 0.f;
+    for (int j = lane; j < N; j += 64) { const float v = x[(size_t)row * N + j]; s += v * v; }
+    const float n = fmaxf(sqrtf(wave_sum(s)), eps);
+    if (lane == 0) norm[row] = n;
+    for (int j = lane; j < N; j += 64) y[(size_t)row * N + j] = x[(size_t)row * N + j] / n;
+  }
+}
+// dx = (dy - y * (y . dy)) / n   (rows whose norm was clamped get dx = dy / eps, like torch)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                          const float* __restrict__ norm, float* __restrict__ dx,
+                                                          int M, int N, float eps) {
+  const int lane = threadIdx.x & 63;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+    const float n = norm[row];
+    float d = 0.f;
+    if (n > eps)
+      for (int j = lane; j < N; j += 64) d += y[(size_t)row * N + j] * dy[(size_t)row * N + j];
+    d = wave_sum(d);
+    for (int j = lane; j < N; j += 64)
+      dx[(size_t)row * N + j] = (dy[(size_t)row * N + j] - y[(size_t)row * N + j] * d) / n;
+  }
+}
+
 // one block; thread per sample; deterministic block tree for the mean
 __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ in,
                                                              const int64_t* __restrict__ labels, int B, int C, int mode,
@@ -210,6 +238,27 @@ int isic_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
   else if (N <= 512) LAUNCH_LN(8);
   else LAUNCH_LN(16);
 #undef LAUNCH_LN
+  return isic_launch_status();
+}
+
+int isic_l2normalize_fwd(const float* x, float* y, float* norm, int M, int N, float eps, void* stream) {
+  ISIC_CHECK_ARG(M >= 0 && N > 0);
+  if (M == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(x && y && norm);
+  int grid = ceil_div(M, 4);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, y, norm, M, N, eps);
+  return isic_launch_status();
+}
+
+int isic_l2normalize_bwd(const float* dy, const float* y, const float* norm, float* dx, int M, int N, float eps,
+                         void* stream) {
+  ISIC_CHECK_ARG(M >= 0 && N > 0);
+  if (M == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(dy && y && norm && dx);
+  int grid = ceil_div(M, 4);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), dy, y, norm, dx, M, N, eps);
   return isic_launch_status();
 }
 

@@ -6,11 +6,12 @@ Same constructor, ``state_dict`` key names and ``forward(x, edge_index, edge_wei
 (``isic_spmm_csr_f32``), dense layers on exact-fp32 MFMA, LayerNorm/ReLU/dropout/
 residual fused in one kernel, the 4-head attention pool in one launch per batch.
 
-Graph models: ``mlp`` (pure dense, pinned by the reference), ``gcn`` and ``gcnii``
-(PyG ``GCNConv`` / ``GCN2Conv`` semantics restated -- ``torch_geometric`` is absent
-and unpinned in the reference, see oracle/gnn.py).  The edge-softmax / mean /
-sum-aggregation variants (``gat``, ``gatv2``, ``graphsage``, ``gin``, ``transformer``,
-``fagcn``) are not built yet and raise ``NotImplementedError``.
+Graph models: ``mlp`` (pure dense, pinned by the reference), ``gcn``, ``gcnii``,
+``graphsage`` (mean aggregation + L2 normalisation) and ``gin`` (sum aggregation) -- PyG
+``GCNConv`` / ``GCN2Conv`` / ``SAGEConv`` / ``GINConv`` semantics restated
+(``torch_geometric`` is absent and unpinned in the reference, see oracle/gnn.py).  The
+edge-softmax variants (``gat``, ``gatv2``, ``transformer``, ``fagcn``) are not built yet and
+raise ``NotImplementedError``.
 
 Beyond the reference: ``forward`` also takes a batch of graphs (``offsets`` + global node ids,
 or a prebuilt ``GraphBatch``) and returns ``probs[G, C]``.
@@ -24,11 +25,12 @@ import torch.nn as nn
 
 from isic_hip import ops
 from isic_hip.bags import BagOffsets, as_offsets
-from isic_hip.graph import GraphBatch, spmm
+from isic_hip.graph import GraphBatch, l2_normalize, spmm
 from utils_g_mil import _DropoutClock
 
 GNN_TYPES = ("mlp", "gcn", "gat", "gatv2", "gin", "graphsage", "transformer", "fagcn", "gcnii")
-_BUILT = ("mlp", "gcn", "gcnii")
+_BUILT = ("mlp", "gcn", "gcnii", "graphsage", "gin")
+_GRAPH_MODE = {"gcn": "gcn", "gcnii": "gcn", "graphsage": "mean", "gin": "sum"}
 
 
 class _GCNConvParams(nn.Module):
@@ -50,6 +52,25 @@ class _GCN2ConvParams(nn.Module):
         nn.init.xavier_uniform_(self.weight1)
         self.alpha = float(alpha)
         self.beta = math.log(theta / layer + 1.0)
+
+
+class _SAGEConvParams(nn.Module):
+    """PyG ``SAGEConv(aggr='mean', normalize=True)``: ``lin_l`` (neighbour mean, with bias) and
+    ``lin_r`` (root, no bias)."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.lin_l = nn.Linear(in_dim, out_dim, bias=True)
+        self.lin_r = nn.Linear(in_dim, out_dim, bias=False)
+
+
+class _GINConvParams(nn.Module):
+    """PyG ``GINConv(nn, train_eps=True)``: ``eps`` [1] (init 0) and the wrapped ``nn`` Sequential."""
+
+    def __init__(self, mlp):
+        super().__init__()
+        self.nn = mlp
+        self.eps = nn.Parameter(torch.zeros(1))
 
 
 class GraphMIL(nn.Module):
@@ -80,6 +101,10 @@ class GraphMIL(nn.Module):
                 if in_dim != out_dim:
                     raise ValueError("GCNII requires a constant hidden dimension across layers")
                 layer = _GCN2ConvParams(out_dim, gcnii_alpha, gcnii_theta, i + 1)
+            elif self.gnn_type == 'graphsage':                                   # 05:87-88
+                layer = _SAGEConvParams(in_dim, out_dim)
+            elif self.gnn_type == 'gin':                                         # 05:89-93
+                layer = _GINConvParams(nn.Sequential(nn.Linear(in_dim, out_dim), nn.ReLU(), nn.Linear(out_dim, out_dim)))
             else:
                 layer = nn.Sequential(nn.Linear(in_dim, out_dim))
             self.gnn_layers.append(layer)
@@ -113,7 +138,9 @@ class GraphMIL(nn.Module):
             return graph
         if edge_index is None:
             raise ValueError(f"gnn_type '{self.gnn_type}' needs edge_index")
-        return GraphBatch(edge_index, n_nodes, edge_weight)
+        mode = _GRAPH_MODE[self.gnn_type]
+        # 05:184-187 passes edge_weight to gcn / gcnii only
+        return GraphBatch(edge_index, n_nodes, edge_weight if mode == "gcn" else None, mode=mode)
 
     def forward(self, x, edge_index=None, edge_weight=None, offsets=None, graph=None):
         """x[N, D] (+ edge_index[2, E]) -> (probs[C], attention_weights[N, heads]) as the reference
@@ -132,6 +159,13 @@ class GraphMIL(nn.Module):
                 h = ops.linear(h, layer[0].weight, layer[0].bias)
             elif self.gnn_type == 'gcn':
                 h = spmm(ops.linear(h, layer.lin.weight, None), g, bias=layer.bias)
+            elif self.gnn_type == 'graphsage':     # lin_l(mean_j x_j) + lin_r(x_i), then row L2 normalisation
+                h = l2_normalize(ops.linear(spmm(h, g), layer.lin_l.weight, layer.lin_l.bias)
+                                 + ops.linear(h, layer.lin_r.weight, None))
+            elif self.gnn_type == 'gin':           # nn((1 + eps) x_i + sum_j x_j); the eps axpy is a torch op
+                z0 = spmm(h, g) + (1.0 + layer.eps) * h
+                z1 = ops.linear(z0, layer.nn[0].weight, layer.nn[0].bias, ops.ACT_RELU)
+                h = ops.linear(z1, layer.nn[2].weight, layer.nn[2].bias)
             else:  # gcnii: (1-beta) p + beta p W1 with p = (1-alpha) A^ h + alpha x0  ==  p @ ((1-beta) I + beta W1)
                 p = spmm(h, g, alpha=1.0 - layer.alpha, addend=x0, addend_scale=layer.alpha)
                 eye = torch.eye(layer.weight1.shape[0], device=p.device, dtype=torch.float32)

@@ -28,7 +28,11 @@ class GraphBatch:
     """Destination-major CSR (+ its transpose) of a batch of graphs with GCN symmetric
     normalisation and self loops (PyG ``gcn_norm`` semantics, `05_train_gnns.py:82`)."""
 
-    def __init__(self, edge_index, n_nodes, edge_weight=None):
+    MODES = {"gcn": 0, "sum": 1, "mean": 2}
+
+    def __init__(self, edge_index, n_nodes, edge_weight=None, mode="gcn"):
+        """mode 'gcn': self loops + symmetric normalisation (GCNConv / GCN2Conv); 'sum': plain neighbour
+        sum (GINConv); 'mean': neighbour mean (SAGEConv).  'sum'/'mean' keep the edges as given."""
         if edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise ValueError("edge_index must be [2, E]")
         if not edge_index.is_cuda:
@@ -46,8 +50,9 @@ class GraphBatch:
         self.val_t = torch.empty(E + n, device=dev, dtype=torch.float32)
         nbytes = (6 * n + 2 * (E + n) + 64) * 4
         ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-        call("isic_gcn_csr_build", ei[0], ei[1], ew, E, n, self.rowptr, self.col, self.val, self.rowptr_t, self.col_t,
-             self.val_t, ws, nbytes)
+        self.mode = mode
+        call("isic_gcn_csr_build", ei[0], ei[1], ew, E, n, self.MODES[mode], self.rowptr, self.col, self.val,
+             self.rowptr_t, self.col_t, self.val_t, ws, nbytes)
 
 
 class SpmmFn(torch.autograd.Function):
@@ -85,3 +90,29 @@ class SpmmFn(torch.autograd.Function):
 
 def spmm(x, graph, bias=None, alpha=1.0, addend=None, addend_scale=0.0):
     return SpmmFn.apply(x, graph, bias, alpha, addend, addend_scale)
+
+
+class L2NormalizeFn(torch.autograd.Function):
+    """Row-wise x / max(||x||_2, eps): ``F.normalize`` of SAGEConv(normalize=True)."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        _chk(x)
+        x2 = _f32c(x)
+        y = torch.empty_like(x2)
+        n = torch.empty(x2.shape[0], device=x2.device, dtype=torch.float32)
+        call("isic_l2normalize_fwd", x2, y, n, x2.shape[0], x2.shape[1], float(eps))
+        ctx.save_for_backward(y, n)
+        ctx.eps = float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, n = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        call("isic_l2normalize_bwd", _f32c(dy), y, n, dx, y.shape[0], y.shape[1], ctx.eps)
+        return dx, None
+
+
+def l2_normalize(x, eps=1e-12):
+    return L2NormalizeFn.apply(x, eps)

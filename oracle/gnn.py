@@ -12,6 +12,8 @@ PARITY UNPINNED for the message-passing layers: the reference calls
             out[i] = sum_{e: dst=i} w^_e x'[src_e] ; out += bias
   GCN2Conv: beta = log(theta/layer + 1); h = (1-alpha) * A^ x + alpha * x_0;
             out = (1-beta) * h + beta * (h @ weight1)
+  SAGEConv: lin_l(mean_j x_j) + lin_r(x_i), L2-normalised rows (aggr='mean', normalize=True)
+  GINConv : nn((1 + eps) x_i + sum_j x_j), eps trainable, init 0
 The ``mlp`` graph model is pure torch in the reference and IS pinned by
 ``tests/golden/graphmil_mlp_*.npz``.
 """
@@ -68,6 +70,25 @@ def gcn2_conv(x, x0, edge_index, edge_weight, weight1, alpha, theta, layer):
     return (1.0 - beta) * h + beta * (h @ weight1)
 
 
+def sage_conv(x, edge_index, lin_l_w, lin_l_b, lin_r_w):
+    """PyG SAGEConv(aggr='mean', normalize=True): lin_l(mean_{j in N(i)} x_j) + lin_r(x_i), then
+    F.normalize(p=2, dim=-1).  No self loops are added; a node without in-edges aggregates 0."""
+    n = x.size(0)
+    agg = torch.zeros_like(x).index_add_(0, edge_index[1], x[edge_index[0]])
+    deg = torch.zeros(n, dtype=x.dtype).index_add_(0, edge_index[1], torch.ones(edge_index.size(1), dtype=x.dtype))
+    agg = agg / deg.clamp(min=1.0).unsqueeze(1)
+    out = F.linear(agg, lin_l_w, lin_l_b) + F.linear(x, lin_r_w)
+    return F.normalize(out, p=2.0, dim=-1)
+
+
+def gin_conv(x, edge_index, eps, w0, b0, w2, b2):
+    """PyG GINConv(nn, train_eps=True) with nn = Linear-ReLU-Linear (`05_train_gnns.py:89-93`):
+    nn((1 + eps) * x_i + sum_{j in N(i)} x_j)."""
+    agg = torch.zeros_like(x).index_add_(0, edge_index[1], x[edge_index[0]])
+    z = agg + (1.0 + eps) * x
+    return F.linear(F.relu(F.linear(z, w0, b0)), w2, b2)
+
+
 DEFAULT_CFG = dict(  # the 05 call site, `05_train_gnns.py:310-326`
     gnn_type="gcn", gnn_hidden=128, gnn_layers=2, gnn_dropout=0.5, gnn_heads=4,
     gnn_concat=True, gcnii_alpha=0.1, gcnii_theta=0.5, att_dim=128, att_heads=4,
@@ -94,6 +115,16 @@ def graphmil_shapes(input_dim, cfg):
             s[f"gnn_layers.{i}.lin.weight"] = (F_, in_dim)
         elif t == "gcnii":
             s[f"gnn_layers.{i}.weight1"] = (F_, F_)
+        elif t == "graphsage":
+            s[f"gnn_layers.{i}.lin_l.weight"] = (F_, in_dim)
+            s[f"gnn_layers.{i}.lin_l.bias"] = (F_,)
+            s[f"gnn_layers.{i}.lin_r.weight"] = (F_, in_dim)
+        elif t == "gin":
+            s[f"gnn_layers.{i}.eps"] = (1,)
+            s[f"gnn_layers.{i}.nn.0.weight"] = (F_, in_dim)
+            s[f"gnn_layers.{i}.nn.0.bias"] = (F_,)
+            s[f"gnn_layers.{i}.nn.2.weight"] = (F_, F_)
+            s[f"gnn_layers.{i}.nn.2.bias"] = (F_,)
         elif t == "mlp":
             s[f"gnn_layers.{i}.0.weight"] = (F_, in_dim)
             s[f"gnn_layers.{i}.0.bias"] = (F_,)
@@ -143,6 +174,12 @@ def graphmil_forward(p, cfg, x, edge_index=None, edge_weight=None, drop=None):
         elif t == "gcnii":
             h = gcn2_conv(h, x0, edge_index, edge_weight, p[f"gnn_layers.{i}.weight1"],
                           c["gcnii_alpha"], c["gcnii_theta"], i + 1)
+        elif t == "graphsage":
+            h = sage_conv(h, edge_index, p[f"gnn_layers.{i}.lin_l.weight"], p[f"gnn_layers.{i}.lin_l.bias"],
+                          p[f"gnn_layers.{i}.lin_r.weight"])
+        elif t == "gin":
+            h = gin_conv(h, edge_index, p[f"gnn_layers.{i}.eps"], p[f"gnn_layers.{i}.nn.0.weight"],
+                         p[f"gnn_layers.{i}.nn.0.bias"], p[f"gnn_layers.{i}.nn.2.weight"], p[f"gnn_layers.{i}.nn.2.bias"])
         else:
             raise ValueError(f"Unsupported gnn_type: {t}")
         if c["use_layer_norm"]:

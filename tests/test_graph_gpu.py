@@ -126,10 +126,10 @@ def test_graphmil_mlp_golden(tag):
     check_grad(g, "x", x.grad, rtol=5e-4, atol=3e-6)
 
 
-@pytest.mark.parametrize("gtype,L", [("gcn", 3), ("gcnii", 2), ("gcn", 1)])
+@pytest.mark.parametrize("gtype,L", [("gcn", 3), ("gcnii", 2), ("gcn", 1), ("graphsage", 2), ("gin", 2)])
 def test_graphmil_graph_models_vs_oracle(gtype, L):
-    """GCN / GCNII GraphMIL (05 call-site config) forward + every gradient vs oracle/gnn.py on a
-    k-NN graph built by the HIP kernel.  fp32 tolerance 5e-5 / 5e-4 (grads)."""
+    """GCN / GCNII / GraphSAGE / GIN GraphMIL (05 call-site config) forward + every gradient vs
+    oracle/gnn.py on a k-NN graph built by the HIP kernel.  fp32 tolerance 5e-5 / 5e-4 (grads)."""
     import build_graphs as bg
     from gnn_models import GraphMIL
     from isic_hip import ops

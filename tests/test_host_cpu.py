@@ -59,6 +59,9 @@ def test_cpu_tensors_are_rejected_everywhere():
         MultiModalMILNet(hidden_dim=8, att_dim=4, radiomics_dim=4, encoder_layers=((64, 1),))(torch.zeros(2, 2, 3, 32, 32), torch.zeros(2, 4))
     with pytest.raises(NotImplementedError):
         GraphMIL(8, "gat")
+    assert [k for k in GraphMIL(8, "gin", 8, 1).state_dict() if k.startswith("gnn_layers")] == [
+        "gnn_layers.0.eps", "gnn_layers.0.nn.0.weight", "gnn_layers.0.nn.0.bias", "gnn_layers.0.nn.2.weight",
+        "gnn_layers.0.nn.2.bias"]
     with pytest.raises(ValueError):
         GraphMIL(8, "nope")
 
