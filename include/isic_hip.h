@@ -164,11 +164,13 @@ int isic_knn_graph(const float* x, const int64_t* offsets, int G, int D, int k, 
  * pass.  workspace: isic_gcn_csr_workspace_bytes(n_nodes, E) bytes.
  * mode 0 = the GCN normalisation above; mode 1 = plain sum aggregation (val = w, no
  * self loops: GINConv, 05_train_gnns.py:89-93); mode 2 = mean aggregation (val =
- * w / in-degree: SAGEConv(aggr='mean'), 05_train_gnns.py:87-88). */
+ * w / in-degree: SAGEConv(aggr='mean'), 05_train_gnns.py:87-88).
+ * perm_t (optional, [E+n_nodes]): for every slot of the transposed CSR the slot of the
+ * same edge in the destination-major CSR (needed by the attention backward). */
 size_t isic_gcn_csr_workspace_bytes(int64_t n_nodes, int64_t E);
 int isic_gcn_csr_build(const int64_t* src, const int64_t* dst, const float* edge_weight, int64_t E, int64_t n_nodes,
                        int mode, int32_t* rowptr, int32_t* col, float* val, int32_t* rowptr_t, int32_t* col_t,
-                       float* val_t, void* workspace, size_t workspace_bytes, void* stream);
+                       float* val_t, int32_t* perm_t, void* workspace, size_t workspace_bytes, void* stream);
 /* out[i,:] = alpha * sum_{e in row i} val[e] * x[col[e],:] (+ bias) (+ addend_scale*addend[i,:])
  * -- the neighbour gather / segmented sum of GCNConv.propagate
  * (05_train_gnns.py:184-185); GCN2Conv's (1-alpha) A^ x + alpha x_0 with addend.
@@ -176,6 +178,25 @@ int isic_gcn_csr_build(const int64_t* src, const int64_t* dst, const float* edge
 int isic_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, const float* bias,
                       float* out, int64_t n_rows, int F, float alpha, const float* addend, float addend_scale,
                       void* stream);
+
+/* Graph attention (PyG GATConv(heads=H, concat=True, dropout=p) as called at
+ * 05_train_gnns.py:83-86) on the GCN-mode CSR (self loops re-added; `val` unused):
+ *   al[n,h] = <x'[n,h,:], att_src[h,:]>, ar[n,h] = <x'[n,h,:], att_dst[h,:]>        (isic_gat_scores)
+ *   alpha = softmax over the edges into dst of leaky_relu(al[src] + ar[dst], slope), dropout on
+ *   alpha (counter-based, element index = slot*H + h), out[dst,h,:] = sum alpha x'[src,h,:] + bias.
+ * x' is [N, H*F]; alpha[nnz, H] (pre-dropout) is saved for the backward pass, which returns
+ * d x' (aggregation + score paths), d al, d ar and uses de[nnz,H] as scratch; the att_src /
+ * att_dst gradients follow as dal^T x' / dar^T x' per head (isic_gemm_f32). */
+int isic_gat_scores(const float* xp, const float* att_src, const float* att_dst, float* al, float* ar, int64_t N, int H,
+                    int F, void* stream);
+int isic_gat_fwd(const float* xp, const float* al, const float* ar, const int32_t* rowptr, const int32_t* col,
+                 const float* bias, float* out, float* alpha, int64_t N, int H, int F, float negative_slope,
+                 uint32_t drop_threshold, float drop_scale, uint64_t seed, uint64_t stream_id, void* stream);
+int isic_gat_bwd(const float* dout, const float* xp, const float* alpha, const float* al, const float* ar,
+                 const float* att_src, const float* att_dst, const int32_t* rowptr, const int32_t* col,
+                 const int32_t* rowptr_t, const int32_t* col_t, const int32_t* perm_t, float* de, float* dar, float* dal,
+                 float* dxp, int64_t N, int H, int F, float negative_slope, uint32_t drop_threshold, float drop_scale,
+                 uint64_t seed, uint64_t stream_id, void* stream);
 
 /* ------------------------------------------------------------------ patch encoder (bf16 MFMA, NHWC)
  * The reference's encoder is an un-vendored ConvMAE run through torch

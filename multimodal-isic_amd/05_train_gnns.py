@@ -125,7 +125,7 @@ def parse_args(argv=None):
     p.add_argument("--models", nargs="*")
     p.add_argument("--variants", nargs="*", default=graph_variants())
     p.add_argument("--folds", nargs="*", type=int, default=list(range(1)))
-    p.add_argument("--gnn", nargs="+", choices=GNN_TYPES, default=["mlp", "gcn", "gcnii", "graphsage", "gin"])
+    p.add_argument("--gnn", nargs="+", choices=GNN_TYPES, default=["mlp", "gcn", "gcnii", "graphsage", "gin", "gat"])
     p.add_argument("--epochs", type=int, default=1)
     p.add_argument("--patience", type=int, default=16)
     p.add_argument("--min-delta", type=float, default=1e-6)

@@ -268,6 +268,24 @@ __global__ __launch_bounds__(256) void spmm_kernel(const int* __restrict__ rowpt
   }
 }
 
+// perm_t[pt] = CSR slot of the edge held by transposed slot pt (self-loop slots map to each other)
+__global__ void csr_pos_kernel(const int* __restrict__ rowptr, int64_t n, const int* __restrict__ eid,
+                               int* __restrict__ pos_of_edge, int mode) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int e = rowptr[i + 1] - (mode == 0 ? 1 : 0);
+  for (int p = rowptr[i]; p < e; ++p) pos_of_edge[eid[p]] = p;
+}
+__global__ void csr_perm_kernel(const int* __restrict__ rowptr, const int* __restrict__ rowptr_t, int64_t n,
+                                const int* __restrict__ eid_t, const int* __restrict__ pos_of_edge,
+                                int* __restrict__ perm_t, int mode) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int e = rowptr_t[i + 1] - (mode == 0 ? 1 : 0);
+  for (int pt = rowptr_t[i]; pt < e; ++pt) perm_t[pt] = pos_of_edge[eid_t[pt]];
+  if (mode == 0) perm_t[e] = rowptr[i + 1] - 1;
+}
+
 inline int grid_for(int64_t n, int block, int cap = 4096) {
   int64_t g = (n + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -298,13 +316,13 @@ int isic_knn_graph(const float* x, const int64_t* offsets, int G, int D, int k, 
 }
 
 size_t isic_gcn_csr_workspace_bytes(int64_t n_nodes, int64_t E) {
-  // cnt_in, cnt_out, fill_in, fill_out (int) | loopw, dis (float) | eid, eid_t (int, E+n each)
-  return (size_t)(6 * n_nodes + 2 * (E + n_nodes) + 64) * 4;
+  // cnt_in, cnt_out, fill_in, fill_out (int) | loopw, dis (float) | eid, eid_t (int, E+n each) | pos_of_edge (int, E)
+  return (size_t)(6 * n_nodes + 2 * (E + n_nodes) + E + 64) * 4;
 }
 
 int isic_gcn_csr_build(const int64_t* src, const int64_t* dst, const float* edge_weight, int64_t E, int64_t n_nodes,
                        int mode, int32_t* rowptr, int32_t* col, float* val, int32_t* rowptr_t, int32_t* col_t,
-                       float* val_t, void* workspace, size_t workspace_bytes, void* stream) {
+                       float* val_t, int32_t* perm_t, void* workspace, size_t workspace_bytes, void* stream) {
   ISIC_CHECK_ARG(E >= 0 && n_nodes > 0 && rowptr && col && val && rowptr_t && col_t && val_t && workspace);
   ISIC_CHECK_ARG(mode >= 0 && mode <= 2);
   ISIC_CHECK_ARG(E == 0 || (src && dst));
@@ -331,6 +349,12 @@ int isic_gcn_csr_build(const int64_t* src, const int64_t* dst, const float* edge
                      val_t, eid_t, dis, mode);
   hipLaunchKernelGGL(csr_norm_kernel, dim3(g), dim3(256), 0, s, rowptr, rowptr_t, n_nodes, dis, col, val, col_t, val_t,
                      mode);
+  if (perm_t) {
+    int* pos_of_edge = eid_t + (E + n_nodes);
+    hipLaunchKernelGGL(csr_pos_kernel, dim3(g), dim3(256), 0, s, rowptr, n_nodes, eid, pos_of_edge, mode);
+    hipLaunchKernelGGL(csr_perm_kernel, dim3(g), dim3(256), 0, s, rowptr, rowptr_t, n_nodes, eid_t, pos_of_edge, perm_t,
+                       mode);
+  }
   return isic_launch_status();
 }
 

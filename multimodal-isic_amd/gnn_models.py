@@ -7,11 +7,12 @@ Same constructor, ``state_dict`` key names and ``forward(x, edge_index, edge_wei
 residual fused in one kernel, the 4-head attention pool in one launch per batch.
 
 Graph models: ``mlp`` (pure dense, pinned by the reference), ``gcn``, ``gcnii``,
-``graphsage`` (mean aggregation + L2 normalisation) and ``gin`` (sum aggregation) -- PyG
-``GCNConv`` / ``GCN2Conv`` / ``SAGEConv`` / ``GINConv`` semantics restated
-(``torch_geometric`` is absent and unpinned in the reference, see oracle/gnn.py).  The
-edge-softmax variants (``gat``, ``gatv2``, ``transformer``, ``fagcn``) are not built yet and
-raise ``NotImplementedError``.
+``graphsage`` (mean aggregation + L2 normalisation), ``gin`` (sum aggregation) and ``gat``
+(per-destination edge softmax, the reference's tuned graph model) -- PyG ``GCNConv`` /
+``GCN2Conv`` / ``SAGEConv`` / ``GINConv`` / ``GATConv`` semantics restated (``torch_geometric``
+is absent and unpinned in the reference, see oracle/gnn.py).  ``gatv2`` and ``fagcn`` are
+mis-sized / mis-called in the reference itself and, with ``transformer``, are not
+built: they raise ``NotImplementedError``.
 
 Beyond the reference: ``forward`` also takes a batch of graphs (``offsets`` + global node ids,
 or a prebuilt ``GraphBatch``) and returns ``probs[G, C]``.
@@ -25,12 +26,12 @@ import torch.nn as nn
 
 from isic_hip import ops
 from isic_hip.bags import BagOffsets, as_offsets
-from isic_hip.graph import GraphBatch, l2_normalize, spmm
+from isic_hip.graph import GraphBatch, gat_conv, l2_normalize, spmm
 from utils_g_mil import _DropoutClock
 
 GNN_TYPES = ("mlp", "gcn", "gat", "gatv2", "gin", "graphsage", "transformer", "fagcn", "gcnii")
-_BUILT = ("mlp", "gcn", "gcnii", "graphsage", "gin")
-_GRAPH_MODE = {"gcn": "gcn", "gcnii": "gcn", "graphsage": "mean", "gin": "sum"}
+_BUILT = ("mlp", "gcn", "gcnii", "graphsage", "gin", "gat")
+_GRAPH_MODE = {"gcn": "gcn", "gcnii": "gcn", "graphsage": "mean", "gin": "sum", "gat": "gcn"}
 
 
 class _GCNConvParams(nn.Module):
@@ -52,6 +53,21 @@ class _GCN2ConvParams(nn.Module):
         nn.init.xavier_uniform_(self.weight1)
         self.alpha = float(alpha)
         self.beta = math.log(theta / layer + 1.0)
+
+
+class _GATConvParams(nn.Module):
+    """PyG ``GATConv(in, F, heads=H, concat)``: ``att_src`` / ``att_dst`` [1,H,F] (Glorot), ``bias``
+    [H*F] (zeros; [F] when not concatenating), ``lin.weight`` [H*F, in] (Glorot, no bias)."""
+
+    def __init__(self, in_dim, out_dim, heads, concat):
+        super().__init__()
+        self.att_src = nn.Parameter(torch.empty(1, heads, out_dim))
+        self.att_dst = nn.Parameter(torch.empty(1, heads, out_dim))
+        self.bias = nn.Parameter(torch.zeros(heads * out_dim if concat else out_dim))
+        self.lin = nn.Linear(in_dim, heads * out_dim, bias=False)
+        for t in (self.att_src, self.att_dst, self.lin.weight):
+            nn.init.xavier_uniform_(t)
+        self.heads, self.out_dim = heads, out_dim
 
 
 class _SAGEConvParams(nn.Module):
@@ -101,6 +117,11 @@ class GraphMIL(nn.Module):
                 if in_dim != out_dim:
                     raise ValueError("GCNII requires a constant hidden dimension across layers")
                 layer = _GCN2ConvParams(out_dim, gcnii_alpha, gcnii_theta, i + 1)
+            elif self.gnn_type == 'gat':                                         # 05:83-86
+                if not gnn_concat:
+                    raise NotImplementedError("GATConv(concat=False) is not built on the HIP path")
+                layer = _GATConvParams(in_dim, out_dim, gnn_heads, gnn_concat)
+                out_dim *= gnn_heads
             elif self.gnn_type == 'graphsage':                                   # 05:87-88
                 layer = _SAGEConvParams(in_dim, out_dim)
             elif self.gnn_type == 'gin':                                         # 05:89-93
@@ -140,7 +161,7 @@ class GraphMIL(nn.Module):
             raise ValueError(f"gnn_type '{self.gnn_type}' needs edge_index")
         mode = _GRAPH_MODE[self.gnn_type]
         # 05:184-187 passes edge_weight to gcn / gcnii only
-        return GraphBatch(edge_index, n_nodes, edge_weight if mode == "gcn" else None, mode=mode)
+        return GraphBatch(edge_index, n_nodes, edge_weight if self.gnn_type in ("gcn", "gcnii") else None, mode=mode)
 
     def forward(self, x, edge_index=None, edge_weight=None, offsets=None, graph=None):
         """x[N, D] (+ edge_index[2, E]) -> (probs[C], attention_weights[N, heads]) as the reference
@@ -159,6 +180,9 @@ class GraphMIL(nn.Module):
                 h = ops.linear(h, layer[0].weight, layer[0].bias)
             elif self.gnn_type == 'gcn':
                 h = spmm(ops.linear(h, layer.lin.weight, None), g, bias=layer.bias)
+            elif self.gnn_type == 'gat':           # edge softmax over the CSR rows; attention dropout = site 32 + i
+                h = gat_conv(ops.linear(h, layer.lin.weight, None), layer.att_src, layer.att_dst, layer.bias, g,
+                             layer.heads, 0.2, clk.spec(p_drop, 32 + i, tr))
             elif self.gnn_type == 'graphsage':     # lin_l(mean_j x_j) + lin_r(x_i), then row L2 normalisation
                 h = l2_normalize(ops.linear(spmm(h, g), layer.lin_l.weight, layer.lin_l.bias)
                                  + ops.linear(h, layer.lin_r.weight, None))

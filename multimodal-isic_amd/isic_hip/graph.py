@@ -48,11 +48,12 @@ class GraphBatch:
         self.rowptr_t = torch.empty(n + 1, device=dev, dtype=torch.int32)
         self.col_t = torch.empty(E + n, device=dev, dtype=torch.int32)
         self.val_t = torch.empty(E + n, device=dev, dtype=torch.float32)
-        nbytes = (6 * n + 2 * (E + n) + 64) * 4
+        self.perm_t = torch.empty(E + n, device=dev, dtype=torch.int32)   # transposed slot -> CSR slot of the same edge
+        nbytes = int(call("isic_gcn_csr_workspace_bytes", n, E))
         ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
         self.mode = mode
         call("isic_gcn_csr_build", ei[0], ei[1], ew, E, n, self.MODES[mode], self.rowptr, self.col, self.val,
-             self.rowptr_t, self.col_t, self.val_t, ws, nbytes)
+             self.rowptr_t, self.col_t, self.val_t, self.perm_t, ws, nbytes)
 
 
 class SpmmFn(torch.autograd.Function):
@@ -116,3 +117,58 @@ class L2NormalizeFn(torch.autograd.Function):
 
 def l2_normalize(x, eps=1e-12):
     return L2NormalizeFn.apply(x, eps)
+
+
+class GatFn(torch.autograd.Function):
+    """PyG GATConv message passing on a 'gcn'-mode GraphBatch (self loops re-added): per-destination
+    edge softmax of leaky_relu(<x', att_src>[src] + <x', att_dst>[dst]) and the weighted neighbour sum."""
+
+    @staticmethod
+    def forward(ctx, xp, att_src, att_dst, bias, graph, heads, slope, drop):
+        from .ops import NO_DROP
+        _chk(xp, att_src, att_dst, bias)
+        xp = _f32c(xp)
+        N, HF = xp.shape
+        F_ = HF // heads
+        a_s, a_d = _f32c(att_src).reshape(heads, F_), _f32c(att_dst).reshape(heads, F_)
+        drop = drop or NO_DROP
+        dev = xp.device
+        al = torch.empty((N, heads), device=dev, dtype=torch.float32)
+        ar = torch.empty((N, heads), device=dev, dtype=torch.float32)
+        call("isic_gat_scores", xp, a_s, a_d, al, ar, N, heads, F_)
+        nnz = graph.col.numel()
+        alpha = torch.empty((nnz, heads), device=dev, dtype=torch.float32)
+        out = torch.empty_like(xp)
+        call("isic_gat_fwd", xp, al, ar, graph.rowptr, graph.col, _f32c(bias) if bias is not None else None, out, alpha, N,
+             heads, F_, float(slope), drop.threshold, drop.scale, drop.seed, drop.stream)
+        ctx.graph, ctx.cfg = graph, (N, heads, F_, float(slope), drop, bias is not None, att_src.shape)
+        ctx.save_for_backward(xp, a_s, a_d, al, ar, alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .ops import gemm
+        xp, a_s, a_d, al, ar, alpha = ctx.saved_tensors
+        N, H, F_, slope, drop, has_bias, att_shape = ctx.cfg
+        g = ctx.graph
+        dout = _f32c(dout)
+        dev = xp.device
+        de = torch.empty_like(alpha)
+        dar = torch.empty((N, H), device=dev, dtype=torch.float32)
+        dal = torch.empty((N, H), device=dev, dtype=torch.float32)
+        dxp = torch.empty_like(xp)
+        call("isic_gat_bwd", dout, xp, alpha, al, ar, a_s, a_d, g.rowptr, g.col, g.rowptr_t, g.col_t, g.perm_t, de, dar,
+             dal, dxp, N, H, F_, slope, drop.threshold, drop.scale, drop.seed, drop.stream)
+        # d att_src[h,:] = dal[:,h]^T x'[:,h,:]   (strided views: one small GEMM per head)
+        d_as = torch.empty((H, F_), device=dev, dtype=torch.float32)
+        d_ad = torch.empty((H, F_), device=dev, dtype=torch.float32)
+        for h in range(H):
+            xh = xp[:, h * F_:(h + 1) * F_]
+            gemm(dal[:, h:h + 1], xh, trans_a=True, out=d_as[h:h + 1])
+            gemm(dar[:, h:h + 1], xh, trans_a=True, out=d_ad[h:h + 1])
+        db = colsum(dout) if has_bias else None
+        return dxp, d_as.reshape(att_shape), d_ad.reshape(att_shape), db, None, None, None, None
+
+
+def gat_conv(xp, att_src, att_dst, bias, graph, heads, negative_slope=0.2, drop=None):
+    return GatFn.apply(xp, att_src, att_dst, bias, graph, heads, negative_slope, drop)

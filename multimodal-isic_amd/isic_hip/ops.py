@@ -65,8 +65,11 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, out=None, 
         raise ValueError(f"gemm shape mismatch: op(a) is [{M},{K}], op(b) is [{Kb},{N}]")
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
-    call("isic_gemm_f32", int(trans_a), int(trans_b), M, N, K, a, a.stride(0), b, b.stride(0), out, out.stride(0),
-         bias, act, float(beta))
+    for t in (a, b, out):      # row-major with a leading dimension: strided row views are fine, the inner stride is not
+        if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1) or not t.is_cuda or t.dtype != torch.float32:
+            raise IsicHipError("gemm operands must be 2-D fp32 device tensors with unit inner stride")
+    call("isic_gemm_f32", int(trans_a), int(trans_b), M, N, K, a.data_ptr(), max(a.stride(0), a.shape[1]), b.data_ptr(),
+         max(b.stride(0), b.shape[1]), out.data_ptr(), max(out.stride(0), out.shape[1]), bias, act, float(beta))
     return out
 
 

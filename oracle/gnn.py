@@ -12,6 +12,8 @@ PARITY UNPINNED for the message-passing layers: the reference calls
             out[i] = sum_{e: dst=i} w^_e x'[src_e] ; out += bias
   GCN2Conv: beta = log(theta/layer + 1); h = (1-alpha) * A^ x + alpha * x_0;
             out = (1-beta) * h + beta * (h @ weight1)
+  GATConv : edge softmax of leaky_relu(<x',a_src>[src] + <x',a_dst>[dst], 0.2) per destination and head,
+            self loops re-added, dropout on alpha, concat heads, + bias
   SAGEConv: lin_l(mean_j x_j) + lin_r(x_i), L2-normalised rows (aggr='mean', normalize=True)
   GINConv : nn((1 + eps) x_i + sum_j x_j), eps trainable, init 0
 The ``mlp`` graph model is pure torch in the reference and IS pinned by
@@ -70,6 +72,39 @@ def gcn2_conv(x, x0, edge_index, edge_weight, weight1, alpha, theta, layer):
     return (1.0 - beta) * h + beta * (h @ weight1)
 
 
+def gat_conv(x, edge_index, lin_w, att_src, att_dst, bias, heads, negative_slope=0.2, drop=None):
+    """PyG GATConv(in, F, heads, concat=True): x' = lin(x).view(N,H,F); self loops removed then one
+    added per node; e = leaky_relu(<x',att_src>[src] + <x',att_dst>[dst]); alpha = softmax over the
+    edges into dst; (counter-based) dropout on alpha, element index = csr_slot*H + h with the
+    destination-major slot order of the product (edges in edge_index order per row, self loop last);
+    out[dst] = sum alpha x'[src]; concat heads; + bias."""
+    n = x.size(0)
+    xp = F.linear(x, lin_w).view(n, heads, -1)
+    al = (xp * att_src.view(1, heads, -1)).sum(-1)
+    ar = (xp * att_dst.view(1, heads, -1)).sum(-1)
+    keep = edge_index[0] != edge_index[1]
+    loops = torch.arange(n, dtype=edge_index.dtype)
+    src = torch.cat([edge_index[0][keep], loops])
+    dst = torch.cat([edge_index[1][keep], loops])
+    # destination-major slot of every edge (stable sort by dst keeps edge order, loop last)
+    order = torch.argsort(dst, stable=True)
+    slot = torch.empty_like(order)
+    slot[order] = torch.arange(order.numel())
+    e = F.leaky_relu(al[src] + ar[dst], negative_slope)                       # [E', H]
+    emax = torch.full((n, heads), -float("inf"), dtype=x.dtype).scatter_reduce(0, dst.view(-1, 1).expand(-1, heads), e, "amax")
+    ex = torch.exp(e - emax[dst])
+    den = torch.zeros(n, heads, dtype=x.dtype).index_add_(0, dst, ex)
+    alpha = ex / den[dst]
+    if drop is not None and drop["p"] > 0.0:
+        from . import philox
+        nn_ = alpha.shape[0] * heads
+        keep_all = torch.from_numpy(philox.dropout_keep(nn_, drop["p"], drop["seed"], drop["stream"])).view(-1, heads)
+        scale = torch.tensor(float(philox.dropout_scale(drop["p"])), dtype=x.dtype)
+        alpha = torch.where(keep_all[slot], alpha * scale, torch.zeros((), dtype=x.dtype))
+    out = torch.zeros(n, heads, xp.shape[-1], dtype=x.dtype).index_add_(0, dst, alpha.unsqueeze(-1) * xp[src])
+    return out.reshape(n, -1) + bias
+
+
 def sage_conv(x, edge_index, lin_l_w, lin_l_b, lin_r_w):
     """PyG SAGEConv(aggr='mean', normalize=True): lin_l(mean_{j in N(i)} x_j) + lin_r(x_i), then
     F.normalize(p=2, dim=-1).  No self loops are added; a node without in-edges aggregates 0."""
@@ -115,6 +150,14 @@ def graphmil_shapes(input_dim, cfg):
             s[f"gnn_layers.{i}.lin.weight"] = (F_, in_dim)
         elif t == "gcnii":
             s[f"gnn_layers.{i}.weight1"] = (F_, F_)
+        elif t == "gat":
+            hh = c["gnn_heads"]
+            s[f"gnn_layers.{i}.att_src"] = (1, hh, F_)
+            s[f"gnn_layers.{i}.att_dst"] = (1, hh, F_)
+            s[f"gnn_layers.{i}.bias"] = (hh * F_,)
+            s[f"gnn_layers.{i}.lin.weight"] = (hh * F_, in_dim)
+            in_dim = hh * F_
+            continue
         elif t == "graphsage":
             s[f"gnn_layers.{i}.lin_l.weight"] = (F_, in_dim)
             s[f"gnn_layers.{i}.lin_l.bias"] = (F_,)
@@ -131,18 +174,19 @@ def graphmil_shapes(input_dim, cfg):
         else:
             raise ValueError(f"Unsupported gnn_type: {t}")
         in_dim = F_
+    Fo = F_ * c["gnn_heads"] if t == "gat" else F_       # GATConv(concat=True) widens the features, 05:86
     if c["use_layer_norm"]:
         for i in range(c["gnn_layers"]):
-            s[f"layer_norms.{i}.weight"] = (F_,)
-            s[f"layer_norms.{i}.bias"] = (F_,)
+            s[f"layer_norms.{i}.weight"] = (Fo,)
+            s[f"layer_norms.{i}.bias"] = (Fo,)
     for h in range(c["att_heads"]):
-        s[f"attention_layers.{h}.0.weight"] = (c["att_dim"], F_)
+        s[f"attention_layers.{h}.0.weight"] = (c["att_dim"], Fo)
         s[f"attention_layers.{h}.0.bias"] = (c["att_dim"],)
         s[f"attention_layers.{h}.2.weight"] = (1, c["att_dim"])
         s[f"attention_layers.{h}.2.bias"] = (1,)
     cd = c["classifier_dim"]
     if c["classifier_light"]:
-        s["classifier.0.weight"] = (cd, F_)
+        s["classifier.0.weight"] = (cd, Fo)
         s["classifier.0.bias"] = (cd,)
         s["classifier.3.weight"] = (c["num_classes"], cd)
         s["classifier.3.bias"] = (c["num_classes"],)
@@ -174,6 +218,12 @@ def graphmil_forward(p, cfg, x, edge_index=None, edge_weight=None, drop=None):
         elif t == "gcnii":
             h = gcn2_conv(h, x0, edge_index, edge_weight, p[f"gnn_layers.{i}.weight1"],
                           c["gcnii_alpha"], c["gcnii_theta"], i + 1)
+        elif t == "gat":
+            adrop = None
+            if drop is not None and c["gnn_dropout"] > 0:
+                adrop = {"p": c["gnn_dropout"], "seed": drop["seed"], "stream": drop["stream_base"] + 32 + i}
+            h = gat_conv(h, edge_index, p[f"gnn_layers.{i}.lin.weight"], p[f"gnn_layers.{i}.att_src"],
+                         p[f"gnn_layers.{i}.att_dst"], p[f"gnn_layers.{i}.bias"], c["gnn_heads"], 0.2, adrop)
         elif t == "graphsage":
             h = sage_conv(h, edge_index, p[f"gnn_layers.{i}.lin_l.weight"], p[f"gnn_layers.{i}.lin_l.bias"],
                           p[f"gnn_layers.{i}.lin_r.weight"])

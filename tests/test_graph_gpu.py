@@ -126,14 +126,14 @@ def test_graphmil_mlp_golden(tag):
     check_grad(g, "x", x.grad, rtol=5e-4, atol=3e-6)
 
 
-@pytest.mark.parametrize("gtype,L", [("gcn", 3), ("gcnii", 2), ("gcn", 1), ("graphsage", 2), ("gin", 2)])
+@pytest.mark.parametrize("gtype,L", [("gcn", 3), ("gcnii", 2), ("gcn", 1), ("graphsage", 2), ("gin", 2), ("gat", 2)])
 def test_graphmil_graph_models_vs_oracle(gtype, L):
     """GCN / GCNII / GraphSAGE / GIN GraphMIL (05 call-site config) forward + every gradient vs
     oracle/gnn.py on a k-NN graph built by the HIP kernel.  fp32 tolerance 5e-5 / 5e-4 (grads)."""
     import build_graphs as bg
     from gnn_models import GraphMIL
     from isic_hip import ops
-    N, D, F_ = 196, 96, 64
+    N, D, F_ = 196, 96, (32 if gtype == "gat" else 64)
     cfg = dict(gnn_type=gtype, gnn_hidden=F_, gnn_layers=L, att_dim=32, classifier_dim=48)
     shapes = gnn.graphmil_shapes(D, cfg)
     p = formula.formula_state_dict(shapes)
@@ -193,3 +193,25 @@ def test_graphmil_batched_equals_per_graph_and_dropout_oracle():
     pr, _ = m(xs[0].to(DEV), eis[0].to(DEV))
     o = gnn.graphmil_forward(p, cfg, xs[0], eis[0], drop={"seed": 321, "stream_base": 3 * 1024})
     assert_close(pr, o["probs"], rtol=5e-5, atol=2e-6, what="dropout probs")
+
+
+def test_gat_attention_dropout_matches_oracle():
+    """Train-mode GAT: dropout on the attention coefficients (counter-based, indexed by CSR slot) and on
+    the node features reproduces the oracle with the same words; graph with self loops and an isolated node."""
+    from gnn_models import GraphMIL
+    D, F_ = 24, 16
+    cfg = dict(gnn_type="gat", gnn_hidden=F_, gnn_layers=2, att_dim=8, classifier_dim=12, gnn_dropout=0.5, gnn_heads=4)
+    p = formula.formula_state_dict(gnn.graphmil_shapes(D, cfg))
+    m = GraphMIL(input_dim=D, gnn_type="gat", gnn_hidden=F_, gnn_layers=2, gnn_dropout=0.5, gnn_heads=4, att_dim=8,
+                 att_heads=4, pool_dropout=0.2, classifier_dim=12, classifier_light=True, num_classes=7)
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == list(gnn.graphmil_shapes(D, cfg).items())
+    m.load_state_dict(p)
+    m = m.to(DEV).train()
+    m.set_dropout_state(seed=77, step=2)
+    gen = torch.Generator().manual_seed(4)
+    n = 30
+    x = torch.randn(n, D, generator=gen)
+    ei = _rand_graph(n - 1, 120, gen)
+    pr, _ = m(x.to(DEV), ei.to(DEV))
+    o = gnn.graphmil_forward(p, cfg, x, ei, drop={"seed": 77, "stream_base": 2 * 1024})
+    assert_close(pr, o["probs"], rtol=5e-5, atol=2e-6, what="gat dropout probs")

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert L.fn["isic_abi_version"]() == 1
     assert L.fn["isic_target_arch"]() == b"gfx950"
     # argument validation happens before any device work: usable without a GPU
-    assert L.fn["isic_gcn_csr_workspace_bytes"](10, 20) == (6 * 10 + 2 * 30 + 64) * 4
+    assert L.fn["isic_gcn_csr_workspace_bytes"](10, 20) == (6 * 10 + 2 * 30 + 20 + 64) * 4
     assert L.fn["isic_gemm_f32"](0, 0, -1, 4, 4, None, 4, None, 4, None, 4, None, 0, 0.0, None) == -1
     assert L.fn["isic_conv2d_igemm_bf16"](1, 1, 1, 1, 8, 8, 48, 8, 8, 64, 3, 3, 1, 1, 1, None, None, None, 0, None) == -2   # Cin % 64
     assert L.fn["isic_conv2d_wgrad_workspace_bytes"](2, 64, 7, 7, 64, 3, 3) >= 2 * 49 * 8
@@ -58,7 +58,7 @@ def test_cpu_tensors_are_rejected_everywhere():
     with pytest.raises(IsicHipError):
         MultiModalMILNet(hidden_dim=8, att_dim=4, radiomics_dim=4, encoder_layers=((64, 1),))(torch.zeros(2, 2, 3, 32, 32), torch.zeros(2, 4))
     with pytest.raises(NotImplementedError):
-        GraphMIL(8, "gat")
+        GraphMIL(8, "gatv2")
     assert [k for k in GraphMIL(8, "gin", 8, 1).state_dict() if k.startswith("gnn_layers")] == [
         "gnn_layers.0.eps", "gnn_layers.0.nn.0.weight", "gnn_layers.0.nn.0.bias", "gnn_layers.0.nn.2.weight",
         "gnn_layers.0.nn.2.bias"]
