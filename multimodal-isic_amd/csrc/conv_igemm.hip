@@ -381,7 +381,20 @@ inline int conv_mode() {
   return g_conv_variant;
 }
 
+int g_conv_c64 = -1;      // halo-resident 3x3 kernel for the 64 -> 64 layers (conv_c64.hip); env ISIC_CONV_C64=0 disables
+inline bool conv_c64_enabled() {
+  if (g_conv_c64 < 0) {
+    const char* e = getenv("ISIC_CONV_C64");
+    g_conv_c64 = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_conv_c64 != 0;
+}
+
 }  // namespace
+
+int isic_conv3x3_c64_launch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int H, int W,
+                            const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots,
+                            hipStream_t stream);
 
 extern "C" {
 
@@ -395,6 +408,12 @@ int isic_conv2d_igemm_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out,
   ISIC_CHECK_ARG(!stat_sum || (stat_slots > 0 && down == 1));
   if (Cin % 64 != 0 || Cout % 64 != 0) return ISIC_ERR_UNSUPPORTED;
   if ((int64_t)N * Hout * Wout > 0x7FFFFFFFLL || (int64_t)N * Hin * Win > 0x7FFFFFFFLL) return ISIC_ERR_UNSUPPORTED;
+  if (Cin == 64 && Cout == 64 && Kh == 3 && Kw == 3 && up == 1 && down == 1 && pad == 1 && Hin == Hout && Win == Wout &&
+      conv_c64_enabled()) {
+    const int rc = isic_conv3x3_c64_launch(in, w, out, N, Hin, Win, addend, stat_sum, stat_sumsq, stat_slots,
+                                           as_stream(stream));
+    return rc != ISIC_OK ? rc : isic_launch_status();
+  }
   ConvArgs a;
   a.in = in; a.w = w; a.out = out; a.addend = addend;
   a.stat_sum = stat_sum; a.stat_sumsq = stat_sumsq; a.stat_slots = stat_slots > 0 ? stat_slots : 1;
@@ -430,7 +449,9 @@ int isic_conv2d_igemm_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out,
 }
 
 int isic_debug_set_conv_variant(int v) {
-  g_conv_variant = v;
+  // 0..3: staging mode of the generic kernel; +10: additionally route the 64 -> 64 3x3 layers through it
+  g_conv_c64 = v >= 10 ? 0 : 1;
+  g_conv_variant = v >= 10 ? v - 10 : v;
   return ISIC_OK;
 }
 

@@ -51,6 +51,9 @@ CONV_CASES = [  # N, H, W, Cin, Cout, k, stride, pad
     (5, 7, 7, 256, 512, 3, 2, 1),
     (1, 14, 14, 512, 512, 3, 1, 1),
     (4, 9, 11, 128, 64, 3, 1, 1),      # non-square, Cout 64 path
+    (2, 13, 37, 64, 64, 3, 1, 1),      # halo-resident 64 -> 64 kernel: ragged 8 x 32 tiles both ways
+    (3, 7, 5, 64, 64, 3, 1, 1),        # ... image smaller than one tile
+    (1, 56, 56, 64, 64, 3, 1, 1),      # ... the layer1 shape
 ]
 
 
