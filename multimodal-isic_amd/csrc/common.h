@@ -44,6 +44,12 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
 }
 
 // ---------------------------------------------------------------- wave reductions (64 lanes)
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits for every
+// global store the wave has in flight -- a full memory round trip when it follows an epilogue's output stores.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

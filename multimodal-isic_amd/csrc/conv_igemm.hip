@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         acc[i][j][2] += __uint_as_float(v[1] << 16);
         acc[i][j][3] += __uint_as_float(v[1] & 0xFFFF0000u);
       }
-    __syncthreads();
+    lds_barrier();
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -291,30 +291,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       v[1] = (unsigned)f32_to_bf16_bits(acc[i][j][2]) | ((unsigned)f32_to_bf16_bits(acc[i][j][3]) << 16);
       *reinterpret_cast<u32x2*>(Cs + crow0 + i * 16 * CPAD + j * 16) = v;
     }
-  __syncthreads();
-  for (int idx = tid; idx < BM * CHUNKS; idx += 256) {
-    const int row = idx / CHUNKS, ch = idx - row * CHUNKS;
-    const int m = m0 + row;
-    if (m < a.M) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(Cs + row * CPAD + ch * 8);
-      const size_t pix = dense ? (size_t)m : out_index(m);
-      *reinterpret_cast<u32x4*>(a.out + pix * a.Cout + n0 + ch * 8) = v;
-    }
-  }
+  lds_barrier();
   if (a.stat_sum) {
-    // per-channel sum / sum of squares of the ROUNDED outputs of this tile (rows >= M are exact zeros)
+    // per-channel sum / sum of squares of the ROUNDED outputs of this tile (rows >= M are exact zeros);
+    // done BEFORE the output stores so that no barrier has to wait for stores in flight
     constexpr int PARTS = 256 / BN;           // threads per column
     constexpr int RPP = BM / PARTS;           // rows per thread
     const int col = tid % BN, part = tid / BN;
     float s = 0.f, q = 0.f;
+#pragma unroll 16
     for (int r = part * RPP; r < (part + 1) * RPP; ++r) {
       const float v = bfbits(Cs[r * CPAD + col]);
       s += v; q += v * v;
     }
-    __syncthreads();
     float* red = reinterpret_cast<float*>(smem + BM * CPAD * 2);   // behind the C tile: 2*256 floats
     red[tid] = s; red[256 + tid] = q;
-    __syncthreads();
+    lds_barrier();
     if (tid < BN) {
       double ds = 0.0, dq = 0.0;
 #pragma unroll
@@ -322,6 +314,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       const size_t slot = (size_t)(blockIdx.x % a.stat_slots) * a.Cout + n0 + tid;
       atomicAdd(a.stat_sum + slot, ds);
       atomicAdd(a.stat_sumsq + slot, dq);
+    }
+  }
+  for (int idx = tid; idx < BM * CHUNKS; idx += 256) {
+    const int row = idx / CHUNKS, ch = idx - row * CHUNKS;
+    const int m = m0 + row;
+    if (m < a.M) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(Cs + row * CPAD + ch * 8);
+      const size_t pix = dense ? (size_t)m : out_index(m);
+      *reinterpret_cast<u32x4*>(a.out + pix * a.Cout + n0 + ch * 8) = v;
     }
   }
 }
@@ -381,18 +382,21 @@ inline int conv_mode() {
   return g_conv_variant;
 }
 
-int g_conv_c64 = -1;      // halo-resident 3x3 kernel for the 64 -> 64 layers (conv_c64.hip); env ISIC_CONV_C64=0 disables
-inline bool conv_c64_enabled() {
+// halo-resident 3x3 kernels for the 64 -> 64 layers (conv_c64.hip): 0 = off (generic kernel), 1 = tile per block,
+// 2 = persistent blocks; env ISIC_CONV_C64
+int g_conv_c64 = -1;
+constexpr int kDefaultConvC64 = 2;
+inline int conv_c64_variant() {
   if (g_conv_c64 < 0) {
     const char* e = getenv("ISIC_CONV_C64");
-    g_conv_c64 = (e && e[0] == '0') ? 0 : 1;
+    g_conv_c64 = (e && e[0] >= '0' && e[0] <= '2') ? (e[0] - '0') : kDefaultConvC64;
   }
-  return g_conv_c64 != 0;
+  return g_conv_c64;
 }
 
 }  // namespace
 
-int isic_conv3x3_c64_launch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int H, int W,
+int isic_conv3x3_c64_launch(int variant, const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int H, int W,
                             const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots,
                             hipStream_t stream);
 
@@ -409,8 +413,8 @@ int isic_conv2d_igemm_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out,
   if (Cin % 64 != 0 || Cout % 64 != 0) return ISIC_ERR_UNSUPPORTED;
   if ((int64_t)N * Hout * Wout > 0x7FFFFFFFLL || (int64_t)N * Hin * Win > 0x7FFFFFFFLL) return ISIC_ERR_UNSUPPORTED;
   if (Cin == 64 && Cout == 64 && Kh == 3 && Kw == 3 && up == 1 && down == 1 && pad == 1 && Hin == Hout && Win == Wout &&
-      conv_c64_enabled()) {
-    const int rc = isic_conv3x3_c64_launch(in, w, out, N, Hin, Win, addend, stat_sum, stat_sumsq, stat_slots,
+      conv_c64_variant() != 0) {
+    const int rc = isic_conv3x3_c64_launch(conv_c64_variant(), in, w, out, N, Hin, Win, addend, stat_sum, stat_sumsq, stat_slots,
                                            as_stream(stream));
     return rc != ISIC_OK ? rc : isic_launch_status();
   }
@@ -449,9 +453,11 @@ int isic_conv2d_igemm_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out,
 }
 
 int isic_debug_set_conv_variant(int v) {
-  // 0..3: staging mode of the generic kernel; +10: additionally route the 64 -> 64 3x3 layers through it
-  g_conv_c64 = v >= 10 ? 0 : 1;
-  g_conv_variant = v >= 10 ? v - 10 : v;
+  // v % 10 in 0..3: staging mode of the generic kernel; v / 10: 0 = default 64 -> 64 kernel, 1 = generic kernel for
+  // those layers too, 2 = tile-per-block halo kernel, 3 = persistent halo kernel
+  const int c = v / 10;
+  g_conv_c64 = c == 0 ? kDefaultConvC64 : c - 1;
+  g_conv_variant = v % 10;
   return ISIC_OK;
 }
 

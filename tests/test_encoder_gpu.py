@@ -116,6 +116,43 @@ def test_conv_dgrad_and_wgrad(case):
     assert_close(dw.cpu(), w.grad, rtol=2e-4, atol=1e-5, what=f"conv wgrad {case}")
 
 
+@pytest.mark.parametrize("variant", [2, 3])                      # 2: tile per block, 3: persistent blocks
+@pytest.mark.parametrize("shape", [(2, 13, 37), (3, 7, 5), (40, 56, 56), (150, 56, 56), (37, 28, 40)])
+def test_conv_c64_kernels_match_generic(variant, shape):
+    """The halo-resident 64 -> 64 kernels issue the same MFMA sequence per output as the generic implicit
+    GEMM (taps in order, two k-steps per tap): outputs, fused statistics and addend joins are compared with
+    it bit for bit, at sizes that give a persistent block 1, 2, 3 and many tiles (the counted-waitcnt paths)."""
+    from isic_hip.lib import call
+    N, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, H, W, 64, generator=g).to(DEV).to(BF)
+    add = torch.randn(N, H, W, 64, generator=g).to(DEV).to(BF)
+    wf = (torch.randn(64, 3, 3, 64, generator=g) / 24).to(DEV).to(BF)
+    slots = 32
+
+    def run(v, addend, stats):
+        call("isic_debug_set_conv_variant", v * 10 + 2)
+        out = torch.empty_like(x)
+        acc = torch.zeros(2, slots, 64, device=DEV, dtype=torch.float64)
+        call("isic_conv2d_igemm_bf16", x, wf, out, N, H, W, 64, H, W, 64, 3, 3, 1, 1, 1, add if addend else None,
+             acc[0] if stats else None, acc[1] if stats else None, slots if stats else 0)
+        torch.cuda.synchronize()
+        return out, acc.sum(1)
+
+    try:
+        for addend, stats in ((False, False), (True, False), (False, True)):
+            ref, racc = run(1, addend, stats)
+            got, gacc = run(variant, addend, stats)
+            assert torch.equal(ref.view(torch.int16), got.view(torch.int16)), \
+                f"variant {variant} addend={addend} stats={stats}: {int((ref != got).sum())} values differ"
+            if stats:
+                o = got.float().reshape(-1, 64).double()
+                assert_close(gacc[0].cpu(), o.sum(0).cpu(), rtol=1e-5, atol=1e-3, what="fused sum")
+                assert_close(gacc[1].cpu(), (o * o).sum(0).cpu(), rtol=1e-5, atol=1e-3, what="fused sumsq")
+    finally:
+        call("isic_debug_set_conv_variant", 2)
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 32), (3, 20, 44), (1, 224, 224)])
 def test_stem_forward_and_wgrad(shape):
     from isic_hip.lib import call
