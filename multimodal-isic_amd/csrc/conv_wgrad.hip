@@ -255,12 +255,33 @@ WgradPlan wgrad_plan(int N, int Cin, int Hout, int Wout, int Cout, int Kh, int K
 
 }  // namespace
 
+// all-taps-per-block kernel of the 64 -> 64 3x3 layers (conv_wgrad_c64.hip)
+size_t isic_wgrad_c64_workspace_bytes(int N, int H, int W);
+int isic_wgrad_c64_launch(const uint16_t* x, const uint16_t* dy, float* dw, int N, int H, int W, void* workspace,
+                          hipStream_t stream);
+
+namespace {
+int g_wgrad_c64 = -1;     // env ISIC_WGRAD_C64=0 routes the 64 -> 64 layers through the generic kernel
+inline bool wgrad_c64_enabled() {
+  if (g_wgrad_c64 < 0) {
+    const char* e = getenv("ISIC_WGRAD_C64");
+    g_wgrad_c64 = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_wgrad_c64 != 0;
+}
+}  // namespace
+
 extern "C" {
 
 size_t isic_conv2d_wgrad_workspace_bytes(int N, int Cin, int Hout, int Wout, int Cout, int Kh, int Kw) {
   if (N <= 0 || Cin <= 0 || Hout <= 0 || Wout <= 0 || Cout <= 0 || Kh <= 0 || Kw <= 0) return 0;
   const WgradPlan p = wgrad_plan(N, Cin, Hout, Wout, Cout, Kh, Kw);
-  return p.table_bytes + 256;
+  size_t need = p.table_bytes + 256;
+  if (Cin == 64 && Cout == 64 && Kh == 3 && Kw == 3) {   // stride 1 / pad 1: input size = output size
+    const size_t c64 = isic_wgrad_c64_workspace_bytes(N, Hout, Wout);
+    if (c64 > need) need = c64;
+  }
+  return need;
 }
 
 int isic_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dw, int N, int Hin, int Win, int Cin,
@@ -273,6 +294,15 @@ int isic_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dw, int
   const int64_t M64 = (int64_t)N * Hout * Wout;
   if (M64 > 0x7FFFFFFFLL / 2 || (int64_t)N * Hin * Win * Cin > 0x7FFFFFFFLL || Hout >= 32768 || Wout >= 32768)
     return ISIC_ERR_UNSUPPORTED;   // 32-bit element offsets / 16-bit packed coordinates
+  if (Cin == 64 && Cout == 64 && Kh == 3 && Kw == 3 && stride == 1 && pad == 1 && Hin == Hout && Win == Wout &&
+      wgrad_c64_enabled()) {
+    const size_t need = isic_wgrad_c64_workspace_bytes(N, Hin, Win);
+    if (need != 0) {
+      if (workspace_bytes < need) return ISIC_ERR_WORKSPACE;
+      const int rc = isic_wgrad_c64_launch(x, dy, dw, N, Hin, Win, workspace, as_stream(stream));
+      return rc != ISIC_OK ? rc : isic_launch_status();
+    }
+  }
   const WgradPlan p = wgrad_plan(N, Cin, Hout, Wout, Cout, Kh, Kw);
   if (workspace_bytes < p.table_bytes) return ISIC_ERR_WORKSPACE;
   WgradArgs a;
