@@ -8,6 +8,6 @@ extern "C" int probe_wc64_run(const uint16_t* x, const uint16_t* dy, float* dw, 
   int rc = isic_wgrad_c64_launch(x, dy, dw, N, H, W, ws, nullptr);
   if (rc) return rc;
   if (hipDeviceSynchronize() != hipSuccess) return -1;
-  return hipMemcpyFromSymbol(stamps_host, HIP_SYMBOL(g_wc64_stamps), sizeof(unsigned long long) * 256 * 64 * 3) == hipSuccess ? 0 : -2;
+  return hipMemcpyFromSymbol(stamps_host, HIP_SYMBOL(g_wc64_stamps), sizeof(unsigned long long) * 256 * 64 * 4) == hipSuccess ? 0 : -2;
 }
 extern "C" size_t probe_wc64_ws(int N, int H, int W) { return isic_wgrad_c64_workspace_bytes(N, H, W); }
