@@ -77,8 +77,10 @@ __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 
 // MODE 0: one LDS stage, register staging      MODE 1: two LDS stages, register staging
 // MODE 2: two LDS stages, LDS-DMA staging       MODE 3: three LDS stages, LDS-DMA, counted vmcnt
+// MODE 4: as MODE 2 with 512 threads: waves 4..7 only issue the LDS-DMA (an LDS-DMA instruction holds its wave for
+//         the order of 100 cycles at issue), waves 0..3 only read LDS and issue MFMAs
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(MODE == 4 ? 512 : 256, MODE == 4 ? 4 : 1) void conv_igemm_kernel(ConvArgs a) {
   constexpr bool DB = (MODE == 1);
   constexpr bool GLDS = (MODE >= 2);
   constexpr int NSTAGE = MODE == 3 ? 3 : (MODE == 0 ? 1 : 2);
@@ -88,7 +90,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   constexpr int CPAD = BN + 8;  // epilogue row stride (elements)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NSTAGE*STAGE, >= C tile
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;   // MODE 4: threads 256..511 mirror 0..255 (staging role)
+  const bool stager = MODE == 4 && threadIdx.x >= 256;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
@@ -203,6 +206,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                                          (lds_ptr)(stage + A_BYTES + (wave * 8 + 32 * i) * 128), 16, 0, 0);
     };
     constexpr int LPT = AROWS + BROWS;        // LDS-DMA instructions per wave per K-tile
+    if (MODE == 4) {
+      if (stager) {
+        if (a.Ktiles > 0) issue(0, smem);
+        for (int kt = 0; kt < a.Ktiles; ++kt) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile kt landed (this wave's rows)
+          __builtin_amdgcn_s_barrier();                        // ... every row; and the MFMA waves are done with stage (kt+1)&1
+          if (kt + 1 < a.Ktiles) issue(kt + 1, smem + ((kt + 1) & 1) * STAGE);
+        }
+        __builtin_amdgcn_s_barrier();                          // matches the MFMA waves' barrier behind the K loop
+        return;                                                // the epilogue belongs to the MFMA waves
+      }
+      for (int kt = 0; kt < a.Ktiles; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        unsigned char* As = smem + (kt & 1) * STAGE;
+        compute(As, As + A_BYTES);
+      }
+      __builtin_amdgcn_s_barrier();                            // all MFMA waves are done reading the stages
+    } else {
 #pragma unroll
     for (int s_ = 0; s_ < NSTAGE - 1; ++s_)
       if (s_ < a.Ktiles) issue(s_, smem + s_ * STAGE);
@@ -216,6 +237,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       compute(As, As + A_BYTES);
     }
     __syncthreads();
+    }
   } else if (DB) {
     // variant 1: two LDS stages, one register set, one barrier per K-tile
     if (a.Ktiles > 0) {   // a parity class of a strided data gradient can have no tap at all
@@ -349,6 +371,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
   constexpr int STAGE = (BM + BN) * BK * 2;
   constexpr int CBYTES = BM * (BN + 8) * 2 + 2 * 256 * 4;
   constexpr int MAIN = (MODE == 3 ? 3 : (MODE == 0 ? 1 : 2)) * STAGE;
+  constexpr int THREADS = MODE == 4 ? 512 : 256;
   constexpr int LDS = MAIN > CBYTES ? MAIN : CBYTES;
   static bool attr_done = false;
   if (!attr_done) {
@@ -358,7 +381,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     attr_done = true;
   }
   dim3 grid(ceil_div(a.M, BM), a.Cout / BN);
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MODE>), grid, dim3(256), LDS, s, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MODE>), grid, dim3(THREADS), LDS, s, a);
   return ISIC_OK;
 }
 
@@ -368,16 +391,17 @@ int launch_conv_mode(int mode, const ConvArgs& a, hipStream_t s) {
     case 1: return launch_conv<BM, BN, WM, WN, 1>(a, s);
     case 2: return launch_conv<BM, BN, WM, WN, 2>(a, s);
     case 3: return launch_conv<BM, BN, WM, WN, 3>(a, s);
+    case 4: return launch_conv<BM, BN, WM, WN, 4>(a, s);
     default: return launch_conv<BM, BN, WM, WN, 0>(a, s);
   }
 }
 
 int g_conv_variant = -1;  // staging MODE of conv_igemm_kernel; -1 = not chosen yet (env ISIC_CONV_MODE or default)
-constexpr int kDefaultConvMode = 2;   // LDS-DMA, two stages: fastest measured (tools/kernel_bench.py)
+constexpr int kDefaultConvMode = 4;   // LDS-DMA, two stages, dedicated staging waves: fastest measured (tools/kernel_bench.py)
 inline int conv_mode() {
   if (g_conv_variant < 0) {
     const char* e = getenv("ISIC_CONV_MODE");
-    g_conv_variant = (e && e[0] >= '0' && e[0] <= '3') ? (e[0] - '0') : kDefaultConvMode;
+    g_conv_variant = (e && e[0] >= '0' && e[0] <= '4') ? (e[0] - '0') : kDefaultConvMode;
   }
   return g_conv_variant;
 }
