@@ -11,6 +11,8 @@ and the autograd edge to the MIL head.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -79,6 +81,7 @@ class ResNet18Encoder(nn.Module):
                 inp = planes
         self._wcache = {}      # conv name -> (w_fwd bf16, w_dgrad bf16)
         self._wgrad_ws = None
+        self._side = None             # second HIP stream: weight gradients run beside the data-gradient chain
         self.grad_ready_hook = None   # callable(list_of_param_names) fired as gradients complete (DDP overlap)
 
     # parameters are registered under dotted torchvision names via nested holder modules
@@ -169,7 +172,32 @@ class ResNet18Encoder(nn.Module):
             p.grad = torch.zeros_like(p.data, memory_format=torch.preserve_format)
         return p.grad
 
+    def _side_stream(self, device):
+        """Weight gradients are leaves of the backward graph: they run on a second stream, so that the
+        MFMA-bound wgrad kernels overlap the HBM-bound BatchNorm passes of the data-gradient chain and
+        fill the partial last round of its convolution grids.  ISIC_WGRAD_STREAM=0 keeps one stream."""
+        if os.environ.get("ISIC_WGRAD_STREAM", "1") == "0":
+            return None
+        if self._side is None or self._side.device != device:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
+
+    def _on_side(self, device, tensors, fn):
+        """Run ``fn`` (kernel launches reading ``tensors``, produced on the current stream) on the side stream."""
+        side = self._side_stream(device)
+        if side is None:
+            fn()
+            return
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            fn()
+        for t in tensors:
+            t.record_stream(side)     # the caching allocator must not hand the block out before the side work is done
+
     def _conv_wgrad(self, x, dy, name):
+        self._on_side(x.device, (x, dy), lambda: self._conv_wgrad_now(x, dy, name))
+
+    def _conv_wgrad_now(self, x, dy, name):
         sp = self.specs[name]
         p = self._get(name + ".weight")
         g = self._grad_buffer(p)
@@ -228,7 +256,10 @@ class ResNet18Encoder(nn.Module):
 
     def _fire(self, names):
         if self.grad_ready_hook is not None:
-            self.grad_ready_hook(names)
+            # the hook hands gradients to the collective stream, which waits for the stream it is called on:
+            # the side stream, once it has caught up with everything the main stream produced so far
+            dev = self._get("conv1.weight").device
+            self._on_side(dev, (), lambda: self.grad_ready_hook(names))
 
     # ------------------------------------------------------------------ forward / backward
     def pack_input(self, images):
@@ -328,8 +359,11 @@ class ResNet18Encoder(nn.Module):
         x0 = tape["x0"]
         p = self._get("conv1.weight")
         gw = self._grad_buffer(p)
-        call("isic_conv_stem_wgrad_bf16", x0, dc, gw, N, x0.shape[1], x0.shape[2], Ho, Wo)
+        self._on_side(dc.device, (x0, dc),
+                      lambda: call("isic_conv_stem_wgrad_bf16", x0, dc, gw, N, x0.shape[1], x0.shape[2], Ho, Wo))
         self._fire(["conv1.weight", "bn1.weight", "bn1.bias"])
+        if self._side is not None:
+            torch.cuda.current_stream(dc.device).wait_stream(self._side)   # gradients complete for whoever comes next
 
     def forward(self, images):
         if torch.is_grad_enabled() and self.training:
