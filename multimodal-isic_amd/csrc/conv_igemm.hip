@@ -77,21 +77,31 @@ __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 
 // MODE 0: one LDS stage, register staging      MODE 1: two LDS stages, register staging
 // MODE 2: two LDS stages, LDS-DMA staging       MODE 3: three LDS stages, LDS-DMA, counted vmcnt
-// MODE 4: as MODE 2 with 512 threads: waves 4..7 only issue the LDS-DMA (an LDS-DMA instruction holds its wave for
-//         the order of 100 cycles at issue), waves 0..3 only read LDS and issue MFMAs
+// MODE 4: as MODE 2 with dedicated STAGING WAVES behind the MFMA waves: they only issue the LDS-DMA (an LDS-DMA
+//         instruction holds its wave for the order of 100 cycles at issue), the MFMA waves only read LDS and multiply
+// MODE 5: staging waves and THREE stages (the DMA of K-tile kt+2 is issued while kt is multiplied: with two stages
+//         the DMA latency of every K-tile is exposed behind the barrier); used with the 256 x 128 tile, 8 + 8 waves
+#ifdef IGEMM_STAMPS   // tests/probes/probe_igemm_stamps.hip: per K-tile clocks of one MFMA wave (slots 0-2) and one staging wave (3-6)
+__device__ unsigned long long g_igemm_stamps[256 * 40 * 8];
+#define IG_STAMP(kt, k, who) do { if (threadIdx.x == (who) && blockIdx.x < 256 && blockIdx.y == 0 && (kt) < 40) g_igemm_stamps[(blockIdx.x * 40 + (kt)) * 8 + (k)] = clock64(); } while (0)
+#else
+#define IG_STAMP(kt, k, who) do { } while (0)
+#endif
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE>
-__global__ __launch_bounds__(MODE == 4 ? 512 : 256, MODE == 4 ? 4 : 1) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__((MODE >= 4 ? 2 : 1) * WAVES_M * WAVES_N * 64, MODE >= 4 ? 4 : 1) void conv_igemm_kernel(ConvArgs a) {
   constexpr bool DB = (MODE == 1);
   constexpr bool GLDS = (MODE >= 2);
-  constexpr int NSTAGE = MODE == 3 ? 3 : (MODE == 0 ? 1 : 2);
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  constexpr int NSTAGE = (MODE == 3 || MODE == 5) ? 3 : (MODE == 0 ? 1 : 2);
+  constexpr int MT = WAVES_M * WAVES_N * 64;          // MFMA threads; MODE >= 4: as many staging threads behind them
   static_assert(BM == WAVES_M * 64 && BN == WAVES_N * 64, "64x64 per wave");
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int CPAD = BN + 8;  // epilogue row stride (elements)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NSTAGE*STAGE, >= C tile
 
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;   // MODE 4: threads 256..511 mirror 0..255 (staging role)
-  const bool stager = MODE == 4 && threadIdx.x >= 256;
+  const bool stager = MODE >= 4 && threadIdx.x >= MT;
+  const int tid = stager ? threadIdx.x - MT : threadIdx.x;   // index inside the role
+  const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
@@ -100,7 +110,8 @@ __global__ __launch_bounds__(MODE == 4 ? 512 : 256, MODE == 4 ? 4 : 1) void conv
   // (ti,tj) is (hrow + dh(ti), wrow + dw(tj)) with a per-tap uniform (dh, dw), so a row carries its
   // element offset at (dh, dw) = (0, 0) plus one validity bit per tap row / tap column; inside the K loop a
   // row costs two bit tests, one add and one select.
-  constexpr int AROWS = BM / 32, BROWS = BN / 32;
+  constexpr int RPP = MT / 8;                          // rows staged per pass: 8 threads per 128-byte row
+  constexpr int AROWS = BM / RPP, BROWS = BN / RPP;
   const int sr = tid >> 3;
   const int sc = GLDS ? ((tid & 7) ^ (sr & 7)) : (tid & 7);   // global 16-byte chunk this thread fetches
   const int ds_ = a.down_shift;
@@ -112,7 +123,7 @@ __global__ __launch_bounds__(MODE == 4 ? 512 : 256, MODE == 4 ? 4 : 1) void conv
   unsigned a_vh[AROWS], a_vw[AROWS];   // bit ti: 0 <= hrow + dh0 + dstep*ti < Hin ; bit tj likewise for columns
 #pragma unroll
   for (int i = 0; i < AROWS; ++i) {
-    const int m = m0 + sr + 32 * i;
+    const int m = m0 + sr + RPP * i;
     a_off[i] = 0; a_vh[i] = 0u; a_vw[i] = 0u;
     if (m < a.M) {
       const int n = (int)fastdiv40((unsigned)m, a.magic_hw);
@@ -127,7 +138,7 @@ __global__ __launch_bounds__(MODE == 4 ? 512 : 256, MODE == 4 ? 4 : 1) void conv
   const size_t Ktot = (size_t)a.Kh * a.Kw * a.Cin;
   const unsigned short* wrow_ptr[BROWS];
 #pragma unroll
-  for (int i = 0; i < BROWS; ++i) wrow_ptr[i] = a.w + (size_t)(n0 + sr + 32 * i) * Ktot + sc * 8;
+  for (int i = 0; i < BROWS; ++i) wrow_ptr[i] = a.w + (size_t)(n0 + sr + RPP * i) * Ktot + sc * 8;
 
   u32x4 ra0[AROWS], rb0[BROWS];
   auto gload = [&](int kt, u32x4 (&ra)[AROWS], u32x4 (&rb)[BROWS]) {
@@ -147,12 +158,12 @@ __global__ __launch_bounds__(MODE == 4 ? 512 : 256, MODE == 4 ? 4 : 1) void conv
   auto lstore = [&](unsigned char* As, unsigned char* Bs, const u32x4 (&ra)[AROWS], const u32x4 (&rb)[BROWS]) {
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
-      const int r = sr + 32 * i;
+      const int r = sr + RPP * i;
       *reinterpret_cast<u32x4*>(As + r * 128 + ((sc ^ (r & 7)) << 4)) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) {
-      const int r = sr + 32 * i;
+      const int r = sr + RPP * i;
       *reinterpret_cast<u32x4*>(Bs + r * 128 + ((sc ^ (r & 7)) << 4)) = rb[i];
     }
   };
@@ -198,29 +209,41 @@ __global__ __launch_bounds__(MODE == 4 ? 512 : 256, MODE == 4 ? 4 : 1) void conv
       for (int i = 0; i < AROWS; ++i) {
         const bool ok = ((a_vh[i] >> ti) & (a_vw[i] >> tj)) & 1u;
         const void* src = ok ? (const void*)(a.in + (a_off[i] + toff)) : (const void*)zp;
-        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(stage + (wave * 8 + 32 * i) * 128), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(stage + (wave * 8 + RPP * i) * 128), 16, 0, 0);
       }
 #pragma unroll
       for (int i = 0; i < BROWS; ++i)
         __builtin_amdgcn_global_load_lds((gbl_ptr)(wrow_ptr[i] + koff),
-                                         (lds_ptr)(stage + A_BYTES + (wave * 8 + 32 * i) * 128), 16, 0, 0);
+                                         (lds_ptr)(stage + A_BYTES + (wave * 8 + RPP * i) * 128), 16, 0, 0);
     };
     constexpr int LPT = AROWS + BROWS;        // LDS-DMA instructions per wave per K-tile
-    if (MODE == 4) {
+    if (MODE >= 4) {
+      // stage of K-tile kt: kt % NSTAGE; the staging waves run NSTAGE-1 tiles ahead of the MFMA waves
       if (stager) {
-        if (a.Ktiles > 0) issue(0, smem);
+#pragma unroll
+        for (int s_ = 0; s_ < NSTAGE - 1; ++s_)
+          if (s_ < a.Ktiles) issue(s_, smem + s_ * STAGE);
         for (int kt = 0; kt < a.Ktiles; ++kt) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile kt landed (this wave's rows)
-          __builtin_amdgcn_s_barrier();                        // ... every row; and the MFMA waves are done with stage (kt+1)&1
-          if (kt + 1 < a.Ktiles) issue(kt + 1, smem + ((kt + 1) & 1) * STAGE);
+          IG_STAMP(kt, 3, MT);
+          // tile kt landed (this wave's rows) when only the younger tiles' DMAs are in flight
+          if (NSTAGE == 3 && kt + 1 < a.Ktiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          IG_STAMP(kt, 4, MT);
+          __builtin_amdgcn_s_barrier();                        // ... every row; and the MFMA waves are done with tile kt-1
+          IG_STAMP(kt, 5, MT);
+          if (kt + NSTAGE - 1 < a.Ktiles) issue(kt + NSTAGE - 1, smem + ((kt + NSTAGE - 1) % NSTAGE) * STAGE);
+          IG_STAMP(kt, 6, MT);
         }
         __builtin_amdgcn_s_barrier();                          // matches the MFMA waves' barrier behind the K loop
         return;                                                // the epilogue belongs to the MFMA waves
       }
       for (int kt = 0; kt < a.Ktiles; ++kt) {
+        IG_STAMP(kt, 0, 0);
         __builtin_amdgcn_s_barrier();
-        unsigned char* As = smem + (kt & 1) * STAGE;
+        IG_STAMP(kt, 1, 0);
+        unsigned char* As = smem + (kt % NSTAGE) * STAGE;
         compute(As, As + A_BYTES);
+        IG_STAMP(kt, 2, 0);
       }
       __builtin_amdgcn_s_barrier();                            // all MFMA waves are done reading the stages
     } else {
@@ -284,7 +307,7 @@ __global__ __launch_bounds__(MODE == 4 ? 512 : 256, MODE == 4 ? 4 : 1) void conv
   const int crow0 = (wm * 64 + fr) * CPAD + wn * 64 + fg * 4;     // element index of tile (0,0)'s 4 values
   if (a.addend) {
     // stage the addend tile (coalesced), add in fp32 in the accumulator domain: ONE rounding
-    for (int idx = tid; idx < BM * CHUNKS; idx += 256) {
+    for (int idx = tid; idx < BM * CHUNKS; idx += MT) {
       const int row = idx / CHUNKS, ch = idx - row * CHUNKS;
       const int m = m0 + row;
       u32x4 v = {0u, 0u, 0u, 0u};
@@ -317,7 +340,7 @@ __global__ __launch_bounds__(MODE == 4 ? 512 : 256, MODE == 4 ? 4 : 1) void conv
   if (a.stat_sum) {
     // per-channel sum / sum of squares of the ROUNDED outputs of this tile (rows >= M are exact zeros);
     // done BEFORE the output stores so that no barrier has to wait for stores in flight
-    constexpr int PARTS = 256 / BN;           // threads per column
+    constexpr int PARTS = MT / BN;            // threads per column
     constexpr int RPP = BM / PARTS;           // rows per thread
     const int col = tid % BN, part = tid / BN;
     float s = 0.f, q = 0.f;
@@ -326,19 +349,19 @@ __global__ __launch_bounds__(MODE == 4 ? 512 : 256, MODE == 4 ? 4 : 1) void conv
       const float v = bfbits(Cs[r * CPAD + col]);
       s += v; q += v * v;
     }
-    float* red = reinterpret_cast<float*>(smem + BM * CPAD * 2);   // behind the C tile: 2*256 floats
-    red[tid] = s; red[256 + tid] = q;
+    float* red = reinterpret_cast<float*>(smem + BM * CPAD * 2);   // behind the C tile: 2*MT floats
+    red[tid] = s; red[MT + tid] = q;
     lds_barrier();
     if (tid < BN) {
       double ds = 0.0, dq = 0.0;
 #pragma unroll
-      for (int p = 0; p < PARTS; ++p) { ds += (double)red[p * BN + tid]; dq += (double)red[256 + p * BN + tid]; }
+      for (int p = 0; p < PARTS; ++p) { ds += (double)red[p * BN + tid]; dq += (double)red[MT + p * BN + tid]; }
       const size_t slot = (size_t)(blockIdx.x % a.stat_slots) * a.Cout + n0 + tid;
       atomicAdd(a.stat_sum + slot, ds);
       atomicAdd(a.stat_sumsq + slot, dq);
     }
   }
-  for (int idx = tid; idx < BM * CHUNKS; idx += 256) {
+  for (int idx = tid; idx < BM * CHUNKS; idx += MT) {
     const int row = idx / CHUNKS, ch = idx - row * CHUNKS;
     const int m = m0 + row;
     if (m < a.M) {
@@ -369,9 +392,10 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, unsigned short* 
 template <int BM, int BN, int WM, int WN, int MODE>
 int launch_conv(const ConvArgs& a, hipStream_t s) {
   constexpr int STAGE = (BM + BN) * BK * 2;
-  constexpr int CBYTES = BM * (BN + 8) * 2 + 2 * 256 * 4;
-  constexpr int MAIN = (MODE == 3 ? 3 : (MODE == 0 ? 1 : 2)) * STAGE;
-  constexpr int THREADS = MODE == 4 ? 512 : 256;
+  constexpr int MT = WM * WN * 64;
+  constexpr int CBYTES = BM * (BN + 8) * 2 + 2 * MT * 4;
+  constexpr int MAIN = ((MODE == 3 || MODE == 5) ? 3 : (MODE == 0 ? 1 : 2)) * STAGE;
+  constexpr int THREADS = (MODE >= 4 ? 2 : 1) * MT;
   constexpr int LDS = MAIN > CBYTES ? MAIN : CBYTES;
   static bool attr_done = false;
   if (!attr_done) {
@@ -397,11 +421,11 @@ int launch_conv_mode(int mode, const ConvArgs& a, hipStream_t s) {
 }
 
 int g_conv_variant = -1;  // staging MODE of conv_igemm_kernel; -1 = not chosen yet (env ISIC_CONV_MODE or default)
-constexpr int kDefaultConvMode = 4;   // LDS-DMA, two stages, dedicated staging waves: fastest measured (tools/kernel_bench.py)
+constexpr int kDefaultConvMode = 5;   // staging waves, three stages, 256 x 128 tile: fastest measured (tools/kernel_bench.py)
 inline int conv_mode() {
   if (g_conv_variant < 0) {
     const char* e = getenv("ISIC_CONV_MODE");
-    g_conv_variant = (e && e[0] >= '0' && e[0] <= '4') ? (e[0] - '0') : kDefaultConvMode;
+    g_conv_variant = (e && e[0] >= '0' && e[0] <= '5') ? (e[0] - '0') : kDefaultConvMode;
   }
   return g_conv_variant;
 }
@@ -469,8 +493,10 @@ int isic_conv2d_igemm_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out,
       // a class without any tap still has to write (addend or zeros): Ktiles == 0 is handled by the kernel
       if (a.nkh > 16 || a.nkw > 16) return ISIC_ERR_UNSUPPORTED;   // per-row tap validity lives in 2 x 16+ bits
       int rc;
-      if (Cout % 128 != 0) rc = launch_conv_mode<256, 64, 4, 1>(conv_mode(), a, s);
-      else rc = launch_conv_mode<128, 128, 2, 2>(conv_mode(), a, s);
+      const int mode = conv_mode();
+      if (Cout % 128 != 0) rc = launch_conv_mode<256, 64, 4, 1>(mode == 5 ? 4 : mode, a, s);
+      else if (mode == 5) rc = launch_conv<256, 128, 4, 2, 5>(a, s);        // 8 MFMA + 8 staging waves, three stages
+      else rc = launch_conv_mode<128, 128, 2, 2>(mode, a, s);
       if (rc != ISIC_OK) return rc;
     }
   return isic_launch_status();

@@ -131,7 +131,7 @@ def test_conv_c64_kernels_match_generic(variant, shape):
     slots = 32
 
     def run(v, addend, stats):
-        call("isic_debug_set_conv_variant", v * 10 + 4)
+        call("isic_debug_set_conv_variant", v * 10 + 5)
         out = torch.empty_like(x)
         acc = torch.zeros(2, slots, 64, device=DEV, dtype=torch.float64)
         call("isic_conv2d_igemm_bf16", x, wf, out, N, H, W, 64, H, W, 64, 3, 3, 1, 1, 1, add if addend else None,
@@ -150,7 +150,7 @@ def test_conv_c64_kernels_match_generic(variant, shape):
                 assert_close(gacc[0].cpu(), o.sum(0).cpu(), rtol=1e-5, atol=1e-3, what="fused sum")
                 assert_close(gacc[1].cpu(), (o * o).sum(0).cpu(), rtol=1e-5, atol=1e-3, what="fused sumsq")
     finally:
-        call("isic_debug_set_conv_variant", 4)
+        call("isic_debug_set_conv_variant", 5)
 
 
 @pytest.mark.parametrize("shape", [(2, 13, 37), (40, 56, 56), (150, 56, 56), (37, 28, 40)])

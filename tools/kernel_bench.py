@@ -38,7 +38,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=512)
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--variant", type=int, default=4)
+    ap.add_argument("--variant", type=int, default=5)
     ap.add_argument("--only", default="", help="substring filter on the conv shape names; also skips the extra kernels")
     a = ap.parse_args()
     call("isic_debug_set_conv_variant", a.variant)
