@@ -278,6 +278,23 @@ int isic_maxpool3x3s2_fwd_bf16(const uint16_t* x, uint16_t* y, uint8_t* argmax, 
                                int Wo, void* stream);
 int isic_maxpool3x3s2_bwd_bf16(const uint8_t* argmax, const uint16_t* dy, uint16_t* dx, int N, int H, int W, int C,
                                int Ho, int Wo, void* stream);
+
+/* Stem fusions (the 112x112x64 stem activation is the largest tensor of the network: 1.6 GB at 1024 images).
+ * y = maxpool3x3s2(relu(x * scale + shift)): BatchNorm apply (net_utils.py / torchvision ResNet.forward: bn1, relu,
+ * maxpool) without materialising the normalised tensor; same values and argmax as isic_bn_apply_bf16 followed by
+ * isic_maxpool3x3s2_fwd_bf16. */
+int isic_bn_relu_maxpool3x3s2_fwd_bf16(const uint16_t* x, const float* scale, const float* shift, uint16_t* y,
+                                       uint8_t* argmax, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+/* BatchNorm(+ReLU, mask recomputed from x) backward whose incoming gradient is the max-pool backward of `dy_pooled`
+ * through `argmax`, gathered on the fly: same results as isic_maxpool3x3s2_bwd_bf16 followed by
+ * isic_bn_bwd_reduce_bf16 / isic_bn_bwd_apply_bf16 (relu = 1, scale/shift given), without the full-size gradient. */
+int isic_bn_bwd_reduce_pooled_bf16(const uint8_t* argmax, const uint16_t* dy_pooled, const uint16_t* x, const float* mean,
+                                   const float* rstd, int N, int H, int W, int C, int Ho, int Wo, const float* scale,
+                                   const float* shift, double* dgamma, double* dbeta, void* stream);
+int isic_bn_bwd_apply_pooled_bf16(const uint8_t* argmax, const uint16_t* dy_pooled, const uint16_t* x, const float* mean,
+                                  const float* rstd, const float* gamma, const double* dgamma, const double* dbeta, int N,
+                                  int H, int W, int C, int Ho, int Wo, const float* scale, const float* shift,
+                                  uint16_t* dx, float* dgamma_f32, float* dbeta_f32, void* stream);
 /* Global average pool NHWC bf16 -> [N,C] fp32, and backward -> bf16. */
 int isic_avgpool_fwd_bf16(const uint16_t* x, float* y, int N, int HW, int C, void* stream);
 int isic_avgpool_bwd_bf16(const float* dy, uint16_t* dx, int N, int HW, int C, void* stream);

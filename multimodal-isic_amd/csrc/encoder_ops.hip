@@ -124,6 +124,40 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
   }
 }
 
+// gather form: each input pixel looks at the <= 2x2 outputs whose window covers it.  Returns the gradient of the
+// 8 channels cg*8.. of input pixel (n, hi, wi), rounded to bf16 like the materialised tensor would be.
+struct PoolGeom { int H, W, C, Ho, Wo; };
+__device__ __forceinline__ void pooled_grad8(const unsigned char* __restrict__ argmax, const unsigned short* __restrict__ dy,
+                                             const PoolGeom& g_, int n, int hi, int wi, int cg, float (&out)[8]) {
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  // outputs ho with ho*2-1 <= hi <= ho*2+1  ->  ho in [ceil((hi-1)/2), floor((hi+1)/2)]
+  const int ho_lo = hi >> 1, ho_hi = (hi + 1) >> 1;
+  const int wo_lo = (wi) >> 1, wo_hi = (wi + 1) >> 1;
+  for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+    if (ho >= g_.Ho) continue;
+    const int kh = hi - (ho * 2 - 1);
+    if (kh < 0 || kh > 2) continue;
+    for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+      if (wo >= g_.Wo) continue;
+      const int kw = wi - (wo * 2 - 1);
+      if (kw < 0 || kw > 2) continue;
+      const int64_t o = (((int64_t)n * g_.Ho + ho) * g_.Wo + wo) * g_.C + cg * 8;
+      const u32x2 am = *reinterpret_cast<const u32x2*>(argmax + o);
+      float g[8];
+      unpack8(*reinterpret_cast<const u32x4*>(dy + o), g);
+      const unsigned code = (unsigned)(kh * 3 + kw);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned b = (am[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+        if (b == code) acc[j] += g[j];
+      }
+    }
+  }
+  unpack8(pack8(acc), out);
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned short* __restrict__ dy,
                                                              const unsigned short* __restrict__ x,
                                                              const unsigned short* __restrict__ y,
@@ -209,8 +243,143 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   }
 }
 
+// ---------------------------------------------------------------- stem: BatchNorm backward fed by the pooled gradient
+// The gradient of the stem activation is the 3x3/2 max-pool backward of the pooled gradient gp through argmax; it is
+// not materialised.  A thread owns the 2x2 input pixels (2a+dy, 2b+dx) of one 8-channel group: they are covered by the
+// pooling windows (a+i, b+j), i, j in {0, 1} only -- window (a, b) covers all four, (a, b+1) the right column,
+// (a+1, b) the lower row, (a+1, b+1) the lower right pixel -- so four (gradient, argmax) loads serve four pixels.
+// Contributions are summed in the order of the materialising kernel and rounded to bf16 like its output.
+__device__ __forceinline__ void pooled_grad_2x2(const unsigned char* __restrict__ argmax, const unsigned short* __restrict__ gp,
+                                                const PoolGeom& g_, int n, int a, int b, int cg, float (&out)[4][8]) {
+  float acc[4][8];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[p][j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jw = 0; jw < 2; ++jw) {
+      const int ho = a + i, wo = b + jw;
+      if (ho >= g_.Ho || wo >= g_.Wo) continue;
+      const int64_t o = (((int64_t)n * g_.Ho + ho) * g_.Wo + wo) * g_.C + cg * 8;
+      const u32x2 am = *reinterpret_cast<const u32x2*>(argmax + o);
+      float g[8];
+      unpack8(*reinterpret_cast<const u32x4*>(gp + o), g);
+#pragma unroll
+      for (int dy = i; dy < 2; ++dy)                    // window row i = 1 only reaches the lower pixels ...
+#pragma unroll
+        for (int dx = jw; dx < 2; ++dx) {               // ... window column 1 only the right ones
+          const unsigned code = (unsigned)((dy + 1 - 2 * i) * 3 + (dx + 1 - 2 * jw));
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const unsigned bsel = (am[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+            if (bsel == code) acc[dy * 2 + dx][j] += g[j];
+          }
+        }
+    }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) unpack8(pack8(acc[p]), out[p]);
+}
+
+__global__ __launch_bounds__(256) void stem_bn_bwd_reduce_kernel(const unsigned char* __restrict__ argmax,
+                                                                  const unsigned short* __restrict__ gp, PoolGeom geom,
+                                                                  const unsigned short* __restrict__ x,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd, int N,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift,
+                                                                  double* __restrict__ dgamma, double* __restrict__ dbeta) {
+  const int C = geom.C, tid = threadIdx.x, cgs = C >> 3, cg = tid % cgs, rl = tid / cgs, rls = 256 / cgs;
+  float acc[2][8], mu[8], rs[8], sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    acc[0][j] = 0.f; acc[1][j] = 0.f; mu[j] = mean[cg * 8 + j]; rs[j] = rstd[cg * 8 + j];
+    sc[j] = scale[cg * 8 + j]; sh[j] = shift[cg * 8 + j];
+  }
+  const int Hb = (geom.H + 1) >> 1, Wb = (geom.W + 1) >> 1;
+  const int64_t nblk = (int64_t)N * Hb * Wb;
+  for (int64_t q = (int64_t)blockIdx.x * rls + rl; q < nblk; q += (int64_t)gridDim.x * rls) {
+    const int b = (int)(q % Wb);
+    const int64_t t = q / Wb;
+    const int a = (int)(t % Hb), n = (int)(t / Hb);
+    float g[4][8];
+    pooled_grad_2x2(argmax, gp, geom, n, a, b, cg, g);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int hi = 2 * a + (p >> 1), wi = 2 * b + (p & 1);
+      if (hi >= geom.H || wi >= geom.W) continue;
+      float xv[8];
+      unpack8(*reinterpret_cast<const u32x4*>(x + (((int64_t)n * geom.H + hi) * geom.W + wi) * C + cg * 8), xv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float dz = (xv[j] * sc[j] + sh[j] > 0.f) ? g[p][j] : 0.f;
+        acc[0][j] += dz * ((xv[j] - mu[j]) * rs[j]);
+        acc[1][j] += dz;
+      }
+    }
+  }
+  double* const dst[2] = {dgamma, dbeta};
+  block_reduce_to_global<2>(acc, C, dst);
+}
+
+__global__ __launch_bounds__(256) void stem_bn_bwd_apply_kernel(
+    const unsigned char* __restrict__ argmax, const unsigned short* __restrict__ gp, PoolGeom geom,
+    const unsigned short* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const double* __restrict__ dgamma, const double* __restrict__ dbeta, int N,
+    const float* __restrict__ scale, const float* __restrict__ shift, unsigned short* __restrict__ dx,
+    float* __restrict__ dgamma_f32, float* __restrict__ dbeta_f32) {
+  const int C = geom.C, cgs = C >> 3;
+  const float inv_rows = 1.f / (float)((int64_t)N * geom.H * geom.W);
+  if (blockIdx.x == 0 && dgamma_f32) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      dgamma_f32[c] += (float)dgamma[c];
+      dbeta_f32[c] += (float)dbeta[c];
+    }
+  }
+  const int cg = threadIdx.x % cgs;           // (the grid stride is a multiple of C/8)
+  float mu[8], rs[8], k1[8], k2[8], k3[8], sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg * 8 + j;
+    mu[j] = mean[c]; rs[j] = rstd[c];
+    k1[j] = gamma[c] * rs[j];
+    k2[j] = (float)dbeta[c] * inv_rows;
+    k3[j] = (float)dgamma[c] * inv_rows;
+    sc[j] = scale[c]; sh[j] = shift[c];
+  }
+  const int Hb = (geom.H + 1) >> 1, Wb = (geom.W + 1) >> 1;
+  const int64_t nvec = (int64_t)N * Hb * Wb * cgs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t q = i / cgs;
+    const int b = (int)(q % Wb);
+    const int64_t t = q / Wb;
+    const int a = (int)(t % Hb), n = (int)(t / Hb);
+    float g[4][8];
+    pooled_grad_2x2(argmax, gp, geom, n, a, b, cg, g);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int hi = 2 * a + (p >> 1), wi = 2 * b + (p & 1);
+      if (hi >= geom.H || wi >= geom.W) continue;
+      const int64_t off = (((int64_t)n * geom.H + hi) * geom.W + wi) * C + cg * 8;
+      float xv[8], o[8];
+      unpack8(*reinterpret_cast<const u32x4*>(x + off), xv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float dz = (xv[j] * sc[j] + sh[j] > 0.f) ? g[p][j] : 0.f;
+        const float xh = (xv[j] - mu[j]) * rs[j];
+        o[j] = k1[j] * (dz - k2[j] - xh * k3[j]);
+      }
+      *reinterpret_cast<u32x4*>(dx + off) = pack8(o);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- pooling
+// scale != nullptr: the input is a raw convolution output and y = maxpool(relu(x * scale + shift)) -- the BatchNorm
+// apply and ReLU of the stem are done on the fly (each value rounded to bf16 as the materialised tensor would be)
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const unsigned short* __restrict__ x,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                            unsigned short* __restrict__ y,
                                                            unsigned char* __restrict__ argmax, int N, int H, int W,
                                                            int C, int Ho, int Wo) {
@@ -222,10 +391,14 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const unsigned short* 
     const int wo = (int)(t % Wo); t /= Wo;
     const int ho = (int)(t % Ho);
     const int n = (int)(t / Ho);
-    float best[8];
+    float best[8], sc[8], sh[8];
     unsigned char bi[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+    if (scale) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sc[j] = scale[cg * 8 + j]; sh[j] = shift[cg * 8 + j]; }
+    }
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       const int hi = ho * 2 - 1 + kh;
@@ -236,6 +409,11 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const unsigned short* 
         if (wi < 0 || wi >= W) continue;
         float f[8];
         unpack8(*reinterpret_cast<const u32x4*>(x + (((int64_t)n * H + hi) * W + wi) * C + cg * 8), f);
+        if (scale) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * sc[j] + sh[j], 0.f);
+          unpack8(pack8(f), f);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           if (f[j] > best[j]) { best[j] = f[j]; bi[j] = (unsigned char)(kh * 3 + kw); }  // first maximum wins
@@ -251,12 +429,12 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const unsigned short* 
   }
 }
 
-// gather form: each input pixel looks at the <= 2x2 outputs whose window covers it
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* __restrict__ argmax,
                                                            const unsigned short* __restrict__ dy,
                                                            unsigned short* __restrict__ dx, int N, int H, int W, int C,
                                                            int Ho, int Wo) {
   const int cgs = C >> 3;
+  const PoolGeom geom{H, W, C, Ho, Wo};
   const int64_t nvec = (int64_t)N * H * W * cgs;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
     const int cg = (int)(i % cgs);
@@ -265,31 +443,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
     const int hi = (int)(t % H);
     const int n = (int)(t / H);
     float acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    // outputs ho with ho*2-1 <= hi <= ho*2+1  ->  ho in [ceil((hi-1)/2), floor((hi+1)/2)]
-    const int ho_lo = hi >> 1, ho_hi = (hi + 1) >> 1;
-    const int wo_lo = (wi) >> 1, wo_hi = (wi + 1) >> 1;
-    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
-      if (ho >= Ho) continue;
-      const int kh = hi - (ho * 2 - 1);
-      if (kh < 0 || kh > 2) continue;
-      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
-        if (wo >= Wo) continue;
-        const int kw = wi - (wo * 2 - 1);
-        if (kw < 0 || kw > 2) continue;
-        const int64_t o = (((int64_t)n * Ho + ho) * Wo + wo) * C + cg * 8;
-        const u32x2 am = *reinterpret_cast<const u32x2*>(argmax + o);
-        float g[8];
-        unpack8(*reinterpret_cast<const u32x4*>(dy + o), g);
-        const unsigned code = (unsigned)(kh * 3 + kw);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const unsigned b = (am[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
-          if (b == code) acc[j] += g[j];
-        }
-      }
-    }
+    pooled_grad8(argmax, dy, geom, n, hi, wi, cg, acc);
     *reinterpret_cast<u32x4*>(dx + i * 8) = pack8(acc);
   }
 }
@@ -409,6 +563,19 @@ int isic_bn_bwd_reduce_bf16(const uint16_t* dy, const uint16_t* x, const uint16_
   return isic_launch_status();
 }
 
+int isic_bn_bwd_reduce_pooled_bf16(const uint8_t* argmax, const uint16_t* dy_pooled, const uint16_t* x, const float* mean,
+                                   const float* rstd, int N, int H, int W, int C, int Ho, int Wo, const float* scale,
+                                   const float* shift, double* dgamma, double* dbeta, void* stream) {
+  ISIC_CHECK_ARG(argmax && dy_pooled && x && mean && rstd && scale && shift && dgamma && dbeta);
+  ISIC_CHECK_ARG(N > 0 && H > 0 && W > 0 && Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1);
+  if (!bn_c_ok(C)) return ISIC_ERR_UNSUPPORTED;
+  const int64_t nblk = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2);
+  const int rls = 256 / (C / 8);
+  hipLaunchKernelGGL(stem_bn_bwd_reduce_kernel, dim3(grid_for(nblk, rls * 2, 2048)), dim3(256), 0, as_stream(stream),
+                     argmax, dy_pooled, PoolGeom{H, W, C, Ho, Wo}, x, mean, rstd, N, scale, shift, dgamma, dbeta);
+  return isic_launch_status();
+}
+
 int isic_bn_bwd_apply_bf16(const uint16_t* dy, const uint16_t* x, const uint16_t* y, const float* mean,
                            const float* rstd, const float* gamma, const double* dgamma, const double* dbeta,
                            int64_t rows, int C, int relu, const float* scale, const float* shift, uint16_t* dx,
@@ -423,13 +590,38 @@ int isic_bn_bwd_apply_bf16(const uint16_t* dy, const uint16_t* x, const uint16_t
   return isic_launch_status();
 }
 
+int isic_bn_bwd_apply_pooled_bf16(const uint8_t* argmax, const uint16_t* dy_pooled, const uint16_t* x, const float* mean,
+                                  const float* rstd, const float* gamma, const double* dgamma, const double* dbeta, int N,
+                                  int H, int W, int C, int Ho, int Wo, const float* scale, const float* shift,
+                                  uint16_t* dx, float* dgamma_f32, float* dbeta_f32, void* stream) {
+  ISIC_CHECK_ARG(argmax && dy_pooled && x && mean && rstd && gamma && dgamma && dbeta && scale && shift && dx);
+  ISIC_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1);
+  ISIC_CHECK_ARG((dgamma_f32 == nullptr) == (dbeta_f32 == nullptr));
+  if (!bn_c_ok(C)) return ISIC_ERR_UNSUPPORTED;
+  const int64_t nvec = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
+  hipLaunchKernelGGL(stem_bn_bwd_apply_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), argmax,
+                     dy_pooled, PoolGeom{H, W, C, Ho, Wo}, x, mean, rstd, gamma, dgamma, dbeta, N, scale, shift, dx,
+                     dgamma_f32, dbeta_f32);
+  return isic_launch_status();
+}
+
 int isic_maxpool3x3s2_fwd_bf16(const uint16_t* x, uint16_t* y, uint8_t* argmax, int N, int H, int W, int C, int Ho,
                                int Wo, void* stream) {
   ISIC_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0);
   ISIC_CHECK_ARG(Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1);
   const int64_t nvec = (int64_t)N * Ho * Wo * (C / 8);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), x, y, argmax, N, H,
-                     W, C, Ho, Wo);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), x, nullptr, nullptr,
+                     y, argmax, N, H, W, C, Ho, Wo);
+  return isic_launch_status();
+}
+
+int isic_bn_relu_maxpool3x3s2_fwd_bf16(const uint16_t* x, const float* scale, const float* shift, uint16_t* y,
+                                       uint8_t* argmax, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
+  ISIC_CHECK_ARG(x && scale && shift && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0);
+  ISIC_CHECK_ARG(Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1);
+  const int64_t nvec = (int64_t)N * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), x, scale, shift, y,
+                     argmax, N, H, W, C, Ho, Wo);
   return isic_launch_status();
 }
 

@@ -213,6 +213,14 @@ class ResNet18Encoder(nn.Module):
 
     def _bn_fwd(self, c, name, relu, residual=None, acc=None):
         """Returns (y, (mean, rstd, scale, shift)).  ``acc`` = fused statistics from the producing conv."""
+        st = self._bn_affine(c, name, acc)
+        N, H, W, C = c.shape
+        y = _empty(c.shape, c)
+        call("isic_bn_apply_bf16", c, st[2], st[3], residual, y, N * H * W, C, int(relu))
+        return y, st
+
+    def _bn_affine(self, c, name, acc=None):
+        """Batch statistics (train) or running statistics (eval) -> (mean, rstd, scale, shift) of y = c*scale + shift."""
         N, H, W, C = c.shape
         rows = N * H * W
         gamma, beta = self._get(name + ".weight"), self._get(name + ".bias")
@@ -233,9 +241,7 @@ class ResNet18Encoder(nn.Module):
         else:
             call("isic_bn_eval_affine", gamma.data, beta.data, self._get(name + ".running_mean"),
                  self._get(name + ".running_var"), BN_EPS, C, scale, shift)
-        y = _empty(c.shape, c)
-        call("isic_bn_apply_bf16", c, scale, shift, residual, y, rows, C, int(relu))
-        return y, (mean, rstd, scale, shift)
+        return mean, rstd, scale, shift
 
     def _bn_bwd(self, dy, c, y, st, name, relu, want_residual, mask_from_x=False):
         """BatchNorm(+ReLU) backward.  ``mask_from_x``: no residual was added, so the ReLU mask is
@@ -286,12 +292,14 @@ class ResNet18Encoder(nn.Module):
         ws, _ = self._weights("conv1", False)
         c = _empty((N, Ho, Wo, 64), x0)
         call("isic_conv_stem_fwd_bf16", x0, ws, c, N, H, W, Ho, Wo)
-        y, st0 = self._bn_fwd(c, "bn1", True)
+        # bn1 + relu + maxpool in one pass over the stem activation (the largest tensor of the network): the
+        # normalised tensor is never written; backward recomputes the ReLU mask from c
+        st0 = self._bn_affine(c, "bn1")
         Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
-        p = _empty((N, Hp, Wp, 64), y)
-        am = torch.empty((N, Hp, Wp, 64), device=y.device, dtype=torch.uint8) if save else None
-        call("isic_maxpool3x3s2_fwd_bf16", y, p, am, N, Ho, Wo, 64, Hp, Wp)
-        tape = {"x0": x0, "stem": (c, y, st0, am, (N, Ho, Wo, 64)), "blocks": []} if save else None
+        p = _empty((N, Hp, Wp, 64), c)
+        am = torch.empty((N, Hp, Wp, 64), device=c.device, dtype=torch.uint8) if save else None
+        call("isic_bn_relu_maxpool3x3s2_fwd_bf16", c, st0[2], st0[3], p, am, N, Ho, Wo, 64, Hp, Wp)
+        tape = {"x0": x0, "stem": (c, st0, am, (N, Ho, Wo, 64)), "blocks": []} if save else None
         x = p
         for pre, ds in self.blocks:
             idn, cd, std = x, None, None
@@ -350,12 +358,17 @@ class ResNet18Encoder(nn.Module):
             del dc1
             g = dx
             self._fire(names)
-        c, y, st0, am, yshape = tape["stem"]
+        c, st0, am, yshape = tape["stem"]
         N, Ho, Wo, _ = yshape
         _, Hp, Wp, _ = g.shape
-        dy = _empty(yshape, g)
-        call("isic_maxpool3x3s2_bwd_bf16", am, g, dy, N, Ho, Wo, 64, Hp, Wp)
-        dc, _ = self._bn_bwd(dy, c, y, st0, "bn1", True, False, mask_from_x=True)
+        # max-pool backward gathered inside the BatchNorm backward passes: no full-size gradient tensor
+        mean, rstd, scale, shift = st0
+        gamma, beta = self._get("bn1.weight"), self._get("bn1.bias")
+        acc = torch.zeros(2, 64, device=c.device, dtype=torch.float64)
+        call("isic_bn_bwd_reduce_pooled_bf16", am, g, c, mean, rstd, N, Ho, Wo, 64, Hp, Wp, scale, shift, acc[0], acc[1])
+        dc = _empty(c.shape, c)
+        call("isic_bn_bwd_apply_pooled_bf16", am, g, c, mean, rstd, gamma.data, acc[0], acc[1], N, Ho, Wo, 64, Hp, Wp,
+             scale, shift, dc, self._grad_buffer(gamma), self._grad_buffer(beta))
         x0 = tape["x0"]
         p = self._get("conv1.weight")
         gw = self._grad_buffer(p)
