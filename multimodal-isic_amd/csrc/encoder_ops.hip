@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const unsigned short* __r
   float acc[2][8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; }
+#pragma unroll 4
   for (int64_t r = (int64_t)blockIdx.x * rls + rl; r < rows; r += (int64_t)gridDim.x * rls) {
     float f[8];
     unpack8(*reinterpret_cast<const u32x4*>(x + r * C + cg * 8), f);
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
   float sc[8], sh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { sc[j] = scale[cg * 8 + j]; sh[j] = shift[cg * 8 + j]; }
+#pragma unroll 2
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
     float f[8], rsd[8];
     unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), f);
@@ -120,7 +122,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
       if (relu) v = fmaxf(v, 0.f);
       f[j] = v;
     }
-    *reinterpret_cast<u32x4*>(y + i * 8) = pack8(f);
+    // streaming store: the tensor is far larger than L2 / MALL and is not read again by this kernel
+    __builtin_nontemporal_store(pack8(f), reinterpret_cast<u32x4*>(y + i * 8));
   }
 }
 
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned short
     acc[0][j] = 0.f; acc[1][j] = 0.f; mu[j] = mean[cg * 8 + j]; rs[j] = rstd[cg * 8 + j];
     sc[j] = from_x ? scale[cg * 8 + j] : 0.f; sh[j] = from_x ? shift[cg * 8 + j] : 0.f;
   }
+#pragma unroll 2
   for (int64_t r = (int64_t)blockIdx.x * rls + rl; r < rows; r += (int64_t)gridDim.x * rls) {
     float g[8], xv[8], yv[8];
     unpack8(*reinterpret_cast<const u32x4*>(dy + r * C + cg * 8), g);
@@ -223,6 +227,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     k3[j] = (float)dgamma[c] * inv_rows;
     sc[j] = from_x ? scale[c] : 0.f; sh[j] = from_x ? shift[c] : 0.f;
   }
+#pragma unroll 2
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
     float g[8], xv[8], yv[8], o[8];
     unpack8(*reinterpret_cast<const u32x4*>(dy + i * 8), g);
@@ -238,8 +243,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
       const float xh = (xv[j] - mu[j]) * rs[j];
       o[j] = k1[j] * (dz - k2[j] - xh * k3[j]);
     }
-    *reinterpret_cast<u32x4*>(dx + i * 8) = pack8(o);
-    if (d_residual) *reinterpret_cast<u32x4*>(d_residual + i * 8) = pack8(g);
+    // streaming stores: the tensors are far larger than L2 / MALL and are not read again by this kernel
+    __builtin_nontemporal_store(pack8(o), reinterpret_cast<u32x4*>(dx + i * 8));
+    if (d_residual) __builtin_nontemporal_store(pack8(g), reinterpret_cast<u32x4*>(d_residual + i * 8));
   }
 }
 
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(256) void stem_bn_bwd_apply_kernel(
         const float xh = (xv[j] - mu[j]) * rs[j];
         o[j] = k1[j] * (dz - k2[j] - xh * k3[j]);
       }
-      *reinterpret_cast<u32x4*>(dx + off) = pack8(o);
+      __builtin_nontemporal_store(pack8(o), reinterpret_cast<u32x4*>(dx + off));
     }
   }
 }
