@@ -173,10 +173,12 @@ class ResNet18Encoder(nn.Module):
         return p.grad
 
     def _side_stream(self, device):
-        """Weight gradients are leaves of the backward graph: they run on a second stream, so that the
-        MFMA-bound wgrad kernels overlap the HBM-bound BatchNorm passes of the data-gradient chain and
-        fill the partial last round of its convolution grids.  ISIC_WGRAD_STREAM=0 keeps one stream."""
-        if os.environ.get("ISIC_WGRAD_STREAM", "1") == "0":
+        """Weight gradients are leaves of the backward graph: with ISIC_WGRAD_STREAM=1 they run on a second
+        stream, so that the MFMA-bound wgrad kernels overlap the HBM-bound BatchNorm passes of the
+        data-gradient chain and fill the partial last round of its convolution grids (+2 % bags/s on one
+        MI355X).  Off by default: concurrent kernels stretch each other, which blurs per-kernel timings
+        (bench.py's roofline, rocprofv3 summaries)."""
+        if os.environ.get("ISIC_WGRAD_STREAM", "0") != "1":
             return None
         if self._side is None or self._side.device != device:
             self._side = torch.cuda.Stream(device=device)
