@@ -24,6 +24,7 @@ struct GemmArgs {
   int M, N, K, lda, ldb, ldc;
   int transA, transB, act, vecA, vecB;
   float beta;
+  int ksplit, klen;     // blockIdx.z handles k in [z*klen, (z+1)*klen): partial sums are atomically added to a pre-scaled C
 };
 
 // Load 4 consecutive elements (along the contiguous dim) of a row-major matrix
@@ -59,14 +60,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
   const int rowK = tid >> 2, kqK = (tid & 3) * 4;
   const int kR = tid >> 4, rqR = (tid & 15) * 4;
 
-  const int nk = (a.K + BK - 1) / BK;
+  const int kbeg = blockIdx.z * a.klen;                       // klen is a multiple of BK
+  const int kend = min(a.K, kbeg + a.klen);
+  const int nk = (kend - kbeg + BK - 1) / BK;
   float4 ra, rb;
   auto gload = [&](int kt) {
-    const int k0 = kt * BK;
-    if (!a.transA) ra = load4(a.A, a.lda, m0 + rowK, k0 + kqK, a.M, a.K, a.vecA);
-    else ra = load4(a.A, a.lda, k0 + kR, m0 + rqR, a.K, a.M, a.vecA);
-    if (a.transB) rb = load4(a.B, a.ldb, n0 + rowK, k0 + kqK, a.N, a.K, a.vecB);
-    else rb = load4(a.B, a.ldb, k0 + kR, n0 + rqR, a.K, a.N, a.vecB);
+    const int k0 = kbeg + kt * BK;
+    if (!a.transA) ra = load4(a.A, a.lda, m0 + rowK, k0 + kqK, a.M, kend, a.vecA);
+    else ra = load4(a.A, a.lda, k0 + kR, m0 + rqR, kend, a.M, a.vecA);
+    if (a.transB) rb = load4(a.B, a.ldb, n0 + rowK, k0 + kqK, a.N, kend, a.vecB);
+    else rb = load4(a.B, a.ldb, k0 + kR, n0 + rqR, kend, a.N, a.vecB);
   };
   auto lstore = [&]() {
     if (!a.transA) *reinterpret_cast<float4*>(&As[rowK * LDT + kqK]) = ra;
@@ -121,26 +124,39 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
         if (a.act == ISIC_ACT_RELU) v = fmaxf(v, 0.f);
         else if (a.act == ISIC_ACT_TANH) v = tanhf(v);
         float* cp = a.C + (size_t)row * a.ldc + col;
+        if (a.ksplit > 1) { atomicAdd(cp, v); continue; }      // C already holds beta * C (gemm_scale_kernel)
         if (a.beta != 0.f) v += a.beta * (*cp);
         *cp = v;
       }
     }
 }
 
+// C[M,N] *= beta (0: zero fill) ahead of a split-K accumulation
+__global__ void gemm_scale_kernel(float* __restrict__ C, int M, int N, int ldc, float beta) {
+  const int64_t n = (int64_t)M * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float* p = C + (i / N) * ldc + (i % N);
+    *p = beta == 0.f ? 0.f : beta * (*p);
+  }
+}
+
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, int ldx,
-                                                      float* __restrict__ out, float beta) {
-  // one block per 64 columns; 4 waves stride the rows; deterministic tree over waves
+                                                      float* __restrict__ out, float beta, int rows_per_block) {
+  // one block per 64 columns x row chunk; 4 waves stride the rows; deterministic tree over waves.  With more than
+  // one row chunk (gridDim.y > 1) the chunk sums are atomically added to the pre-scaled output.
   __shared__ float part[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
   float s = 0.f;
   if (col < N)
-    for (int r = wave; r < M; r += 4) s += X[(size_t)r * ldx + col];
+    for (int r = r0 + wave; r < r1; r += 4) s += X[(size_t)r * ldx + col];
   part[wave][lane] = s;
   __syncthreads();
   if (wave == 0 && col < N) {
     float t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-    out[col] = beta != 0.f ? beta * out[col] + t : t;
+    if (gridDim.y > 1) atomicAdd(out + col, t);
+    else out[col] = beta != 0.f ? beta * out[col] + t : t;
   }
 }
 
@@ -207,6 +223,25 @@ int isic_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, i
   a.vecB = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
   dim3 grid(ceil_div(M, BM), ceil_div(N, BN));
   ISIC_CHECK_ARG(grid.y <= 65535u);
+  // split K when a long reduction meets a small output (weight gradients dW = dY^T X over all the nodes of a batch):
+  // a handful of 64x64 tiles would otherwise walk tens of thousands of k on a handful of CUs
+  a.ksplit = 1; a.klen = ((K + BK - 1) / BK) * BK;
+  const long long tiles = (long long)grid.x * grid.y;
+  if (!bias && act == ISIC_ACT_NONE && K >= 2048 && tiles < 512) {
+    long long want = (1024 + tiles - 1) / tiles;                   // ~4 blocks per CU
+    const long long max_split = K / 256;                           // at least 256 k per split
+    if (want > max_split) want = max_split;
+    if (want > 1) {
+      a.klen = (int)(((K + want - 1) / want + BK - 1) / BK) * BK;
+      a.ksplit = ceil_div(K, a.klen);
+    }
+  }
+  if (a.ksplit > 1) {
+    if (beta != 1.f)
+      hipLaunchKernelGGL(gemm_scale_kernel, dim3(grid_for((int64_t)M * N, 256)), dim3(256), 0, as_stream(stream), C, M, N,
+                         ldc, beta);
+    grid.z = a.ksplit;
+  }
   hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, as_stream(stream), a);
   return isic_launch_status();
 }
@@ -215,7 +250,20 @@ int isic_colsum_f32(const float* X, int M, int N, int ldx, float* out, float bet
   ISIC_CHECK_ARG(M >= 0 && N >= 0 && ldx >= N);
   if (N == 0) return ISIC_OK;
   ISIC_CHECK_ARG(X && out);
-  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64)), dim3(256), 0, as_stream(stream), X, M, N, ldx, out, beta);
+  // few column blocks x many rows (bias gradients over all the nodes of a batch): split the rows over blockIdx.y
+  int chunks = 1;
+  const int colblocks = ceil_div(N, 64);
+  if (M >= 8192 && colblocks < 256) {
+    chunks = (1024 + colblocks - 1) / colblocks;
+    if (chunks > M / 1024) chunks = M / 1024;
+    if (chunks < 1) chunks = 1;
+  }
+  const int rows_per_block = ceil_div(M > 0 ? M : 1, chunks);
+  chunks = ceil_div(M > 0 ? M : 1, rows_per_block);
+  if (chunks > 1)
+    hipLaunchKernelGGL(gemm_scale_kernel, dim3(1), dim3(256), 0, as_stream(stream), out, 1, N, N, beta);
+  hipLaunchKernelGGL(colsum_kernel, dim3(colblocks, chunks), dim3(256), 0, as_stream(stream), X, M, N, ldx, out, beta,
+                     rows_per_block);
   return isic_launch_status();
 }
 

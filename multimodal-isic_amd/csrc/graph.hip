@@ -268,6 +268,71 @@ __global__ __launch_bounds__(256) void spmm_kernel(const int* __restrict__ rowpt
   }
 }
 
+// F <= 256, F % 4 == 0: a GROUP of LPR lanes (16 bytes of the row each) owns an output row, 64 / LPR rows per wave.
+// The one-wave-per-row kernel above walks its ~9 edges through two dependent loads each (column index, then the
+// neighbour row) with nothing else in flight: latency-bound at a tenth of the HBM rate.  Here the group fetches the
+// indices and weights of up to LPR edges with ONE coalesced load, broadcasts them by lane shuffles, and keeps four
+// independent neighbour-row loads in flight.  Accumulation order per row is unchanged (edge order): same results.
+constexpr int SPMM_THREADS = 1024, UNR = 8;
+template <int LPR>
+__global__ __launch_bounds__(SPMM_THREADS) void spmm_group_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                          const float* __restrict__ val, const float* __restrict__ x,
+                                                          const float* __restrict__ bias, float* __restrict__ out,
+                                                          int64_t n_rows, int F, float alpha,
+                                                          const float* __restrict__ addend, float addend_scale) {
+  constexpr int RW = 64 / LPR;
+  const int lane = threadIdx.x & 63, gl = lane & (LPR - 1), g0 = lane - gl;      // lane in group, first lane of the group
+  const int64_t row = ((int64_t)blockIdx.x * (SPMM_THREADS / 64) + (threadIdx.x >> 6)) * RW + (lane / LPR);
+  const bool row_ok = row < n_rows;
+  const int b = row_ok ? rowptr[row] : 0, deg = row_ok ? rowptr[row + 1] - b : 0;
+  const bool fl = gl * 4 < F;                                                     // this lane holds features 4gl .. 4gl+3
+  const float* xl = x + gl * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int base = 0;; base += LPR) {
+    const int cnt = min(LPR, deg - base);                  // edges of this group's row in this chunk (<= 0: none left)
+    int maxcnt = cnt;                                      // wave-uniform trip count: the largest chunk of the wave's rows
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, o, 64));
+    if (maxcnt <= 0) break;
+    int c = 0;
+    float w = 0.f;
+    if (gl < cnt) { c = col[b + base + gl]; w = val[b + base + gl]; }
+    for (int j = 0; j < maxcnt; j += UNR) {
+      int cj[UNR];
+      float wj[UNR];
+      float4 xv[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int src = g0 + ((j + u) & (LPR - 1));
+        cj[u] = __shfl(c, src, 64);
+        wj[u] = __shfl(w, src, 64);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j + u < cnt && fl) xv[u] = *reinterpret_cast<const float4*>(xl + (int64_t)cj[u] * F);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+        if (j + u < cnt) {
+          acc.x += wj[u] * xv[u].x; acc.y += wj[u] * xv[u].y; acc.z += wj[u] * xv[u].z; acc.w += wj[u] * xv[u].w;
+        }
+    }
+  }
+  if (row_ok && fl) {
+    float4 o = make_float4(alpha * acc.x, alpha * acc.y, alpha * acc.z, alpha * acc.w);
+    if (bias) {
+      const float4 bv = *reinterpret_cast<const float4*>(bias + gl * 4);
+      o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+    }
+    if (addend) {
+      const float4 av = *reinterpret_cast<const float4*>(addend + row * F + gl * 4);
+      o.x += addend_scale * av.x; o.y += addend_scale * av.y; o.z += addend_scale * av.z; o.w += addend_scale * av.w;
+    }
+    *reinterpret_cast<float4*>(out + row * F + gl * 4) = o;
+  }
+}
+
 // perm_t[pt] = CSR slot of the edge held by transposed slot pt (self-loop slots map to each other)
 __global__ void csr_pos_kernel(const int* __restrict__ rowptr, int64_t n, const int* __restrict__ eid,
                                int* __restrict__ pos_of_edge, int mode) {
@@ -367,6 +432,16 @@ int isic_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* va
   const dim3 grid((unsigned)((n_rows + 3) / 4));
   hipStream_t s = as_stream(stream);
   const bool al16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  const bool al16_all = al16 && ((reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(addend)) & 15) == 0;
+  if (F % 4 == 0 && F <= 256 && al16_all) {
+    const int lpr = F <= 64 ? 16 : (F <= 128 ? 32 : 64);
+    const int rows_per_block = (SPMM_THREADS / 64) * (64 / lpr);
+    const dim3 g2((unsigned)((n_rows + rows_per_block - 1) / rows_per_block));
+    if (lpr == 16) hipLaunchKernelGGL(spmm_group_kernel<16>, g2, dim3(SPMM_THREADS), 0, s, rowptr, col, val, x, bias, out, n_rows, F, alpha, addend, addend_scale);
+    else if (lpr == 32) hipLaunchKernelGGL(spmm_group_kernel<32>, g2, dim3(SPMM_THREADS), 0, s, rowptr, col, val, x, bias, out, n_rows, F, alpha, addend, addend_scale);
+    else hipLaunchKernelGGL(spmm_group_kernel<64>, g2, dim3(SPMM_THREADS), 0, s, rowptr, col, val, x, bias, out, n_rows, F, alpha, addend, addend_scale);
+    return isic_launch_status();
+  }
   if (F % 4 == 0 && al16 && F >= 256)
     hipLaunchKernelGGL(spmm_kernel<4>, grid, dim3(256), 0, s, rowptr, col, val, x, bias, out, n_rows, F, alpha, addend, addend_scale);
   else if (F % 2 == 0 && al16 && F >= 128)

@@ -123,3 +123,25 @@ def test_cpu_tensor_is_rejected():
     m = utils_g_mil.AttentionMIL_teacher(8, 4, 4, 0.0, 3)
     with pytest.raises(IsicHipError):
         m(torch.zeros(5, 8))
+
+
+@pytest.mark.parametrize("shape", [(128, 200, 20000, True, False), (70, 768, 50176, True, False), (96, 64, 9000, False, True)])
+@pytest.mark.parametrize("beta", [0.0, 1.0, 0.5])
+def test_gemm_split_k_and_chunked_colsum(shape, beta):
+    """Long reductions onto small outputs (the weight / bias gradients over all nodes of a graph batch) are split
+    over K / over row chunks and accumulated with atomics onto the pre-scaled output: compared with fp64."""
+    from isic_hip import ops
+    M, N, K, ta, tb = shape
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn((K, M) if ta else (M, K), generator=g)
+    b = torch.randn((N, K) if tb else (K, N), generator=g)
+    c0 = torch.randn(M, N, generator=g)
+    ref = (a.t() if ta else a).double() @ (b.t() if tb else b).double() + beta * c0.double()
+    out = c0.clone().to(DEV)
+    ops.gemm(a.to(DEV), b.to(DEV), trans_a=ta, trans_b=tb, out=out, beta=beta)
+    assert_close(out.cpu(), ref, rtol=2e-6, atol=1e-4, what=f"split-K gemm {shape} beta={beta}")
+    x = torch.randn(K, N, generator=g)
+    o0 = torch.randn(N, generator=g)
+    o = o0.clone().to(DEV)
+    ops.colsum(x.to(DEV), out=o, beta=beta)
+    assert_close(o.cpu(), x.double().sum(0) + beta * o0.double(), rtol=2e-6, atol=1e-4, what=f"colsum {shape} beta={beta}")
