@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(const int* __restrict__ rowpt
 // neighbour row) with nothing else in flight: latency-bound at a tenth of the HBM rate.  Here the group fetches the
 // indices and weights of up to LPR edges with ONE coalesced load, broadcasts them by lane shuffles, and keeps four
 // independent neighbour-row loads in flight.  Accumulation order per row is unchanged (edge order): same results.
-constexpr int SPMM_THREADS = 1024, UNR = 8;
+constexpr int SPMM_THREADS = 256, UNR = 4;
 template <int LPR>
 __global__ __launch_bounds__(SPMM_THREADS) void spmm_group_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                           const float* __restrict__ val, const float* __restrict__ x,
@@ -282,7 +282,9 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_group_kernel(const int* __r
                                                           const float* __restrict__ addend, float addend_scale) {
   constexpr int RW = 64 / LPR;
   const int lane = threadIdx.x & 63, gl = lane & (LPR - 1), g0 = lane - gl;      // lane in group, first lane of the group
-  const int64_t row = ((int64_t)blockIdx.x * (SPMM_THREADS / 64) + (threadIdx.x >> 6)) * RW + (lane / LPR);
+  const int64_t per_xcd = (gridDim.x + 7) / 8;
+  const int64_t chunk = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);      // may exceed the last chunk: rows >= n_rows
+  const int64_t row = (chunk * (SPMM_THREADS / 64) + (threadIdx.x >> 6)) * RW + (lane / LPR);
   const bool row_ok = row < n_rows;
   const int b = row_ok ? rowptr[row] : 0, deg = row_ok ? rowptr[row + 1] - b : 0;
   const bool fl = gl * 4 < F;                                                     // this lane holds features 4gl .. 4gl+3
@@ -436,7 +438,7 @@ int isic_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* va
   if (F % 4 == 0 && F <= 256 && al16_all) {
     const int lpr = F <= 64 ? 16 : (F <= 128 ? 32 : 64);
     const int rows_per_block = (SPMM_THREADS / 64) * (64 / lpr);
-    const dim3 g2((unsigned)((n_rows + rows_per_block - 1) / rows_per_block));
+    const dim3 g2((unsigned)((((n_rows + rows_per_block - 1) / rows_per_block) + 7) / 8 * 8));   // multiple of 8: bijective XCD remap
     if (lpr == 16) hipLaunchKernelGGL(spmm_group_kernel<16>, g2, dim3(SPMM_THREADS), 0, s, rowptr, col, val, x, bias, out, n_rows, F, alpha, addend, addend_scale);
     else if (lpr == 32) hipLaunchKernelGGL(spmm_group_kernel<32>, g2, dim3(SPMM_THREADS), 0, s, rowptr, col, val, x, bias, out, n_rows, F, alpha, addend, addend_scale);
     else hipLaunchKernelGGL(spmm_group_kernel<64>, g2, dim3(SPMM_THREADS), 0, s, rowptr, col, val, x, bias, out, n_rows, F, alpha, addend, addend_scale);

@@ -98,6 +98,33 @@ def test_gcn_csr_spmm_forward_backward(weighted):
     assert_close(bd.grad, bias.grad, rtol=2e-5, atol=2e-6, what="dbias")
 
 
+@pytest.mark.parametrize("F", [64, 128, 32])
+def test_spmm_large_batch_of_graphs(F):
+    """The grouped-lane SpMM on a batch (>= 512 rows, F <= 128): a ragged batch of small graphs (block-diagonal operator, blocks
+    of rows that straddle two graphs, a few edges far outside any window) vs oracle.gcn_conv, forward and backward."""
+    from isic_hip.graph import GraphBatch, spmm
+    gen = torch.Generator().manual_seed(13)
+    sizes = [int(v) for v in torch.randint(20, 230, (14,), generator=gen)]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    n = int(offs[-1])
+    eis = [_rand_graph(m, 6 * m, gen) + int(o) for m, o in zip(sizes, offs[:-1])]
+    far = torch.stack([torch.randint(0, n, (40,), generator=gen), torch.randint(0, n, (40,), generator=gen)])
+    ei = torch.cat(eis + [far], dim=1)
+    assert n >= 512
+    x = torch.randn(n, F, generator=gen, requires_grad=True)
+    bias = torch.randn(F, generator=gen, requires_grad=True)
+    ref = gnn.gcn_conv(x, ei, None, torch.eye(F), bias)
+    dy = torch.randn(n, F, generator=gen)
+    ref.backward(dy)
+    gb = GraphBatch(ei.to(DEV), n)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    bd = bias.detach().to(DEV).requires_grad_(True)
+    out = spmm(xd, gb, bias=bd)
+    out.backward(dy.to(DEV))
+    assert_close(out, ref, rtol=2e-5, atol=2e-6, what="A^x+b")
+    assert_close(xd.grad, x.grad, rtol=2e-5, atol=2e-6, what="dx")
+
+
 @pytest.mark.parametrize("tag", ["small", "ref", "same"])
 def test_graphmil_mlp_golden(tag):
     from gnn_models import GraphMIL
