@@ -32,7 +32,10 @@ struct PoolArgs {
 // dynamic LDS carve (floats):
 //   w3s[heads*A] | W4s[C*H] | sc[max_bag*heads] | wm[NWAVE*heads] | wl[NWAVE*heads] |
 //   wP[NWAVE*MAX_C] | wz[NWAVE*heads*H]
-template <int JH>
+// JA > 0: A <= 64 * JA -- the attention-hidden values of a row (all heads) are fetched up front together with the
+// h values, so that a row costs ONE memory latency instead of one per head and 64-column slice (the generic loop,
+// JA = 0, was latency-bound at an eighth of the HBM rate on GraphMIL's 4 heads x 128).
+template <int JH, int JA>
 __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(PoolArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = a.H, A = a.A, NH = a.heads, C = a.C;
@@ -69,10 +72,20 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(PoolArgs a) {
     const float* hrow = a.h + (size_t)(lo + n) * H;
     const float* trow = a.t + (size_t)(lo + n) * At + (size_t)a.head0 * A;
     float hreg[JH];
+    float treg[MAX_HEADS][JA > 0 ? JA : 1];
 #pragma unroll
     for (int j = 0; j < JH; ++j) {
       const int col = lane + 64 * j;
       hreg[j] = col < H ? hrow[col] : 0.f;
+    }
+    if (JA > 0) {
+#pragma unroll
+      for (int k = 0; k < MAX_HEADS; ++k)
+#pragma unroll
+        for (int i = 0; i < (JA > 0 ? JA : 1); ++i) {
+          const int j = lane + 64 * i;
+          treg[k][i] = (k < NH && j < A) ? trow[k * A + j] : 0.f;
+        }
     }
     // class-space branch: P[n,c] = W4[c,:] . h[n,:] + b4[c]
     float Pn[MAX_C];
@@ -109,7 +122,15 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(PoolArgs a) {
     for (int k = 0; k < MAX_HEADS; ++k) {
       if (k < NH) {
         float p = 0.f;
-        for (int j = lane; j < A; j += 64) p += trow[k * A + j] * w3s[k * A + j];
+        if (JA > 0) {
+#pragma unroll
+          for (int i = 0; i < (JA > 0 ? JA : 1); ++i) {
+            const int j = lane + 64 * i;
+            if (j < A) p += treg[k][i] * w3s[k * A + j];
+          }
+        } else {
+          for (int j = lane; j < A; j += 64) p += trow[k * A + j] * w3s[k * A + j];
+        }
         const float s = wave_sum(p) + a.b3[a.head0 + k];
         if (lane == 0) sc[n * NH + k] = s;
         const float mn = fmaxf(m[k], s);
@@ -361,14 +382,15 @@ int isic_attn_pool_fwd(const float* h, const float* t, const float* w3, const fl
     const size_t lds = sizeof(float) * ((size_t)nh * A + (W4 ? (size_t)C * H : 0) + (size_t)max_bag * nh +
                                         2 * NWAVE * nh + NWAVE * MAX_C + (size_t)NWAVE * nh * H);
     int rc;
-#define LAUNCH_POOL(JH)                                                                             \
-  rc = ensure_lds(attn_pool_fwd_kernel<JH>, lds);                                                   \
+#define LAUNCH_POOL(JH, JA)                                                                         \
+  rc = ensure_lds(attn_pool_fwd_kernel<JH, JA>, lds);                                               \
   if (rc != ISIC_OK) return rc;                                                                     \
-  hipLaunchKernelGGL(attn_pool_fwd_kernel<JH>, dim3(B), dim3(256), lds, as_stream(stream), a)
-    if (H <= 128) { LAUNCH_POOL(2); }
-    else if (H <= 256) { LAUNCH_POOL(4); }
-    else if (H <= 512) { LAUNCH_POOL(8); }
-    else { LAUNCH_POOL(16); }
+  hipLaunchKernelGGL((attn_pool_fwd_kernel<JH, JA>), dim3(B), dim3(256), lds, as_stream(stream), a)
+    if (H <= 128 && A <= 128) { LAUNCH_POOL(2, 2); }
+    else if (H <= 128) { LAUNCH_POOL(2, 0); }
+    else if (H <= 256) { LAUNCH_POOL(4, 0); }
+    else if (H <= 512) { LAUNCH_POOL(8, 0); }
+    else { LAUNCH_POOL(16, 0); }
 #undef LAUNCH_POOL
     rc = isic_launch_status();
     if (rc != ISIC_OK) return rc;
