@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--k", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--step-graphs", type=int, default=256, help="graphs per optimizer step of the train-step timing")
+    ap.add_argument("--step-only", action="store_true", help="skip the kernel micro-benchmarks (for rocprofv3 of the train step)")
     a = ap.parse_args()
     from isic_hip import ops, optim
     from isic_hip.bags import BagOffsets
@@ -54,8 +55,12 @@ def main():
     offs = BagOffsets.from_lengths([N] * G, dev)
     res = {"graphs_per_launch": G, "nodes": N, "feat": D, "hidden": F, "k": k, "hbm_peak_GBs": HBM_PEAK_GBS}
 
+    if a.step_only:
+        G = a.step_graphs
+        x = x[: G * N]
+        offs = BagOffsets.from_lengths([N] * G, dev)
     # ---- k-NN build (03_build_graphs.py:37-54): compulsory bytes N*D*4 read + N*k*8 written per graph
-    t = timeit(lambda: knn_indices(x, offs, k), a.iters)
+    t = timeit(lambda: knn_indices(x, offs, k), 1 if a.step_only else a.iters)
     nn_idx = knn_indices(x, offs, k)                        # [G*N, k] node ids local to the graph
     nn_idx = nn_idx + (torch.arange(G * N, device=dev) // N * N).view(-1, 1)
     b = G * (N * D * 4 + N * k * 8)
@@ -67,6 +72,8 @@ def main():
     E = ei.shape[1] + G * N                                 # with self loops
 
     # ---- segmented-sum SpMM, forward and backward (GCNConv aggregation, 05_train_gnns.py:82,184-185)
+    if a.step_only:
+        a.iters = 1
     h = torch.randn(G * N, F, device=dev, generator=gen, requires_grad=True)
     comp = G * N * F * 4 * 2 + E * 4 * 2 + (G * N + 1) * 4  # read h + write out + col + val + rowptr
     t = timeit(lambda: spmm(h.detach(), graph), a.iters)
@@ -117,7 +124,7 @@ def main():
         loss = ops.cross_entropy_from_probs(probs, y)
         loss.backward()
         opt.step()
-    t = timeit(step, max(3, a.iters // 2))
+    t = timeit(step, 20 if a.step_only else max(3, a.iters // 2))
     res["graphmil_gcn3_train_step"] = {"graphs_per_step": Gs, "ms": t * 1e3, "graphs_per_s": Gs / t}
     print(json.dumps(res))
 
