@@ -279,6 +279,18 @@ int isic_maxpool3x3s2_fwd_bf16(const uint16_t* x, uint16_t* y, uint8_t* argmax, 
 int isic_maxpool3x3s2_bwd_bf16(const uint8_t* argmax, const uint16_t* dy, uint16_t* dx, int N, int H, int W, int C,
                                int Ho, int Wo, void* stream);
 
+/* ReLU mask as 1 bit per element (bit j of byte [row][C/8] = output channel 8*byte+j is positive): the backward
+ * passes of a BatchNorm + residual + ReLU (BasicBlock.bn2, net: torchvision resnet.py BasicBlock.forward) read it
+ * instead of the full output tensor -- same results as the y-based forms below, ~2 B/element less traffic per pass. */
+int isic_bn_apply_mask_bf16(const uint16_t* x, const float* scale, const float* shift, const uint16_t* residual,
+                            uint16_t* y, uint8_t* relu_mask, int64_t rows, int C, void* stream);
+int isic_bn_bwd_reduce_mask_bf16(const uint16_t* dy, const uint16_t* x, const uint8_t* relu_mask, const float* mean,
+                                 const float* rstd, int64_t rows, int C, double* dgamma, double* dbeta, void* stream);
+int isic_bn_bwd_apply_mask_bf16(const uint16_t* dy, const uint16_t* x, const uint8_t* relu_mask, const float* mean,
+                                const float* rstd, const float* gamma, const double* dgamma, const double* dbeta,
+                                int64_t rows, int C, uint16_t* dx, uint16_t* d_residual, float* dgamma_f32,
+                                float* dbeta_f32, void* stream);
+
 /* Stem fusions (the 112x112x64 stem activation is the largest tensor of the network: 1.6 GB at 1024 images).
  * y = maxpool3x3s2(relu(x * scale + shift)): BatchNorm apply (net_utils.py / torchvision ResNet.forward: bn1, relu,
  * maxpool) without materialising the normalised tensor; same values and argmax as isic_bn_apply_bf16 followed by

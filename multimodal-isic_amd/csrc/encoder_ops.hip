@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ shift,
                                                         const unsigned short* __restrict__ residual,
-                                                        unsigned short* __restrict__ y, int64_t nvec, int C, int relu) {
+                                                        unsigned short* __restrict__ y,
+                                                        unsigned char* __restrict__ relu_mask, int64_t nvec, int C, int relu) {
   // the grid stride (gridDim.x * 256) is a multiple of C/8, so a thread always sees the same 8 channels
   const int cg = threadIdx.x % (C >> 3);
   float sc[8], sh[8];
@@ -121,6 +122,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
       if (residual) v += rsd[j];
       if (relu) v = fmaxf(v, 0.f);
       f[j] = v;
+    }
+    if (relu_mask) {                                      // bit j: output j of this 8-channel vector is positive
+      unsigned m = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m |= (f[j] > 0.f ? 1u : 0u) << j;
+      relu_mask[i] = (unsigned char)m;
     }
     // streaming store: the tensor is far larger than L2 / MALL and is not read again by this kernel
     __builtin_nontemporal_store(pack8(f), reinterpret_cast<u32x4*>(y + i * 8));
@@ -164,6 +171,7 @@ __device__ __forceinline__ void pooled_grad8(const unsigned char* __restrict__ a
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned short* __restrict__ dy,
                                                              const unsigned short* __restrict__ x,
                                                              const unsigned short* __restrict__ y,
+                                                             const unsigned char* __restrict__ relu_mask,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, int64_t rows, int C,
                                                              int relu, const float* __restrict__ scale,
@@ -186,6 +194,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned short
     if (from_x) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) yv[j] = xv[j] * sc[j] + sh[j];
+    } else if (relu_mask) {                                // 1 bit per element instead of re-reading the output
+      const unsigned m = relu_mask[r * (C >> 3) + cg];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) yv[j] = ((m >> j) & 1u) ? 1.f : 0.f;
     } else if (relu) unpack8(*reinterpret_cast<const u32x4*>(y + r * C + cg * 8), yv);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -200,6 +212,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned short
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x, const unsigned short* __restrict__ y,
+    const unsigned char* __restrict__ relu_mask,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
     const double* __restrict__ dgamma, const double* __restrict__ dbeta, int64_t rows, int C, int relu,
     const float* __restrict__ scale, const float* __restrict__ shift,
@@ -235,6 +248,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     if (from_x) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) yv[j] = xv[j] * sc[j] + sh[j];
+    } else if (relu_mask) {
+      const unsigned m = relu_mask[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) yv[j] = ((m >> j) & 1u) ? 1.f : 0.f;
     } else if (relu) unpack8(*reinterpret_cast<const u32x4*>(y + i * 8), yv);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -552,7 +569,16 @@ int isic_bn_apply_bf16(const uint16_t* x, const float* scale, const float* shift
   ISIC_CHECK_ARG(x && scale && shift && y && rows > 0 && C > 0 && C % 8 == 0);
   const int64_t nvec = rows * (C / 8);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), x, scale, shift,
-                     residual, y, nvec, C, relu);
+                     residual, y, nullptr, nvec, C, relu);
+  return isic_launch_status();
+}
+
+int isic_bn_apply_mask_bf16(const uint16_t* x, const float* scale, const float* shift, const uint16_t* residual,
+                            uint16_t* y, uint8_t* relu_mask, int64_t rows, int C, void* stream) {
+  ISIC_CHECK_ARG(x && scale && shift && y && relu_mask && rows > 0 && C > 0 && C % 8 == 0);
+  const int64_t nvec = rows * (C / 8);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), x, scale, shift,
+                     residual, y, relu_mask, nvec, C, 1);
   return isic_launch_status();
 }
 
@@ -565,7 +591,17 @@ int isic_bn_bwd_reduce_bf16(const uint16_t* dy, const uint16_t* x, const uint16_
   if (!bn_c_ok(C)) return ISIC_ERR_UNSUPPORTED;
   const int rls = 256 / (C / 8);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid_for(rows, rls * 8, 2048)), dim3(256), 0, as_stream(stream), dy, x,
-                     y, mean, rstd, rows, C, relu, scale, shift, dgamma, dbeta);
+                     y, nullptr, mean, rstd, rows, C, relu, scale, shift, dgamma, dbeta);
+  return isic_launch_status();
+}
+
+int isic_bn_bwd_reduce_mask_bf16(const uint16_t* dy, const uint16_t* x, const uint8_t* relu_mask, const float* mean,
+                                 const float* rstd, int64_t rows, int C, double* dgamma, double* dbeta, void* stream) {
+  ISIC_CHECK_ARG(dy && x && relu_mask && mean && rstd && dgamma && dbeta && rows > 0 && C > 0);
+  if (!bn_c_ok(C)) return ISIC_ERR_UNSUPPORTED;
+  const int rls = 256 / (C / 8);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid_for(rows, rls * 8, 2048)), dim3(256), 0, as_stream(stream), dy, x,
+                     nullptr, relu_mask, mean, rstd, rows, C, 1, nullptr, nullptr, dgamma, dbeta);
   return isic_launch_status();
 }
 
@@ -591,8 +627,21 @@ int isic_bn_bwd_apply_bf16(const uint16_t* dy, const uint16_t* x, const uint16_t
   ISIC_CHECK_ARG(!relu || y || scale);
   ISIC_CHECK_ARG((dgamma_f32 == nullptr) == (dbeta_f32 == nullptr));
   const int64_t nvec = rows * (C / 8);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), dy, x, y, mean,
-                     rstd, gamma, dgamma, dbeta, rows, C, relu, scale, shift, dx, d_residual, dgamma_f32, dbeta_f32);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), dy, x, y, nullptr,
+                     mean, rstd, gamma, dgamma, dbeta, rows, C, relu, scale, shift, dx, d_residual, dgamma_f32, dbeta_f32);
+  return isic_launch_status();
+}
+
+int isic_bn_bwd_apply_mask_bf16(const uint16_t* dy, const uint16_t* x, const uint8_t* relu_mask, const float* mean,
+                                const float* rstd, const float* gamma, const double* dgamma, const double* dbeta,
+                                int64_t rows, int C, uint16_t* dx, uint16_t* d_residual, float* dgamma_f32,
+                                float* dbeta_f32, void* stream) {
+  ISIC_CHECK_ARG(dy && x && relu_mask && mean && rstd && gamma && dgamma && dbeta && dx && rows > 0 && C > 0 && C % 8 == 0);
+  ISIC_CHECK_ARG((dgamma_f32 == nullptr) == (dbeta_f32 == nullptr));
+  const int64_t nvec = rows * (C / 8);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), dy, x, nullptr,
+                     relu_mask, mean, rstd, gamma, dgamma, dbeta, rows, C, 1, nullptr, nullptr, dx, d_residual, dgamma_f32,
+                     dbeta_f32);
   return isic_launch_status();
 }
 

@@ -218,6 +218,11 @@ class ResNet18Encoder(nn.Module):
         st = self._bn_affine(c, name, acc)
         N, H, W, C = c.shape
         y = _empty(c.shape, c)
+        if relu and residual is not None and self.training:
+            # the backward passes need the ReLU mask of relu(bn(c) + residual): kept as 1 bit per element
+            mask = torch.empty((N * H * W * C) // 8, device=c.device, dtype=torch.uint8)
+            call("isic_bn_apply_mask_bf16", c, st[2], st[3], residual, y, mask, N * H * W, C)
+            return y, st + (mask,)
         call("isic_bn_apply_bf16", c, st[2], st[3], residual, y, N * H * W, C, int(relu))
         return y, st
 
@@ -248,11 +253,19 @@ class ResNet18Encoder(nn.Module):
     def _bn_bwd(self, dy, c, y, st, name, relu, want_residual, mask_from_x=False):
         """BatchNorm(+ReLU) backward.  ``mask_from_x``: no residual was added, so the ReLU mask is
         recomputed from c*scale+shift and y is not read."""
-        mean, rstd, scale, shift = st
+        mean, rstd, scale, shift = st[:4]
+        mask = st[4] if len(st) > 4 else None
         N, H, W, C = c.shape
         rows = N * H * W
         gamma, beta = self._get(name + ".weight"), self._get(name + ".bias")
         acc = torch.zeros(2, C, device=c.device, dtype=torch.float64)
+        if mask is not None and relu and not mask_from_x:
+            call("isic_bn_bwd_reduce_mask_bf16", dy, c, mask, mean, rstd, rows, C, acc[0], acc[1])
+            dx = _empty(c.shape, c)
+            dres = _empty(c.shape, c) if want_residual else None
+            call("isic_bn_bwd_apply_mask_bf16", dy, c, mask, mean, rstd, gamma.data, acc[0], acc[1], rows, C, dx, dres,
+                 self._grad_buffer(gamma), self._grad_buffer(beta))
+            return dx, dres
         sc, sh = (scale, shift) if (mask_from_x and relu) else (None, None)
         yy = None if (mask_from_x or not relu) else y
         call("isic_bn_bwd_reduce_bf16", dy, c, yy, mean, rstd, rows, C, int(relu), sc, sh, acc[0], acc[1])

@@ -302,6 +302,21 @@ def test_batchnorm_forward_backward(C, relu, res):
     if res:
         d = (from_nhwc(dres) - r.grad).abs()
         assert float((d > 1e-6).float().mean()) < 5e-3
+    if res and relu:
+        # 1-bit ReLU mask variants: bit-identical to the forms that re-read the output tensor
+        ym = torch.empty_like(xd)
+        mask = torch.empty(rows * C // 8, device=DEV, dtype=torch.uint8)
+        call("isic_bn_apply_mask_bf16", xd, scale, shift, nhwc(r.detach()), ym, mask, rows, C)
+        assert torch.equal(ym.view(torch.int16), yd.view(torch.int16))
+        acc3 = torch.zeros(2, C, device=DEV, dtype=torch.float64)
+        call("isic_bn_bwd_reduce_mask_bf16", dyd, xd, mask, mean, rstd, rows, C, acc3[0], acc3[1])
+        assert_close(acc3.cpu(), acc2.cpu(), rtol=1e-6, atol=1e-6, what="mask reduce")
+        dx3, dres3 = torch.empty_like(xd), torch.empty_like(xd)
+        dg3, db3 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        call("isic_bn_bwd_apply_mask_bf16", dyd, xd, mask, mean, rstd, gamma.detach().to(DEV), acc2[0], acc2[1], rows, C,
+             dx3, dres3, dg3, db3)
+        assert torch.equal(dx3.view(torch.int16), dx.view(torch.int16))
+        assert torch.equal(dres3.view(torch.int16), dres.view(torch.int16))
 
 
 def test_pools():
