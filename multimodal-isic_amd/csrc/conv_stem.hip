@@ -33,15 +33,33 @@ struct StemArgs {
   int N, Hin, Win, Hout, Wout, tiles_h, tiles_w, total_tiles;
 };
 
-__device__ __forceinline__ void load_patch(unsigned char* Ps, const StemArgs& a, int n, int oy0, int ox0, int tid) {
-  // patch pixel (pr, pc) = input pixel (2*oy0 - 3 + pr, 2*ox0 - 3 + pc); 8 bytes each
-  for (int idx = tid; idx < PR * PC; idx += 256) {
+// The input patch of a tile, staged in two halves -- global loads into registers, registers into LDS -- so that the
+// loads of the NEXT tile are in flight while the current tile is multiplied (PR * PC = 840 pixels: at most 4 per thread).
+// patch pixel (pr, pc) = input pixel (2*oy0 - 3 + pr, 2*ox0 - 3 + pc); 8 bytes each
+constexpr int PATCH_PER_THREAD = (PR * PC + 255) / 256;
+__device__ __forceinline__ void fetch_patch(u32x2 (&r)[PATCH_PER_THREAD], const StemArgs& a, int tile, int tid) {
+  const int n = tile / (a.tiles_h * a.tiles_w);
+  const int t2 = tile - n * (a.tiles_h * a.tiles_w);
+  const int oy0 = (t2 / a.tiles_w) * TH, ox0 = (t2 % a.tiles_w) * TW;
+#pragma unroll
+  for (int u = 0; u < PATCH_PER_THREAD; ++u) {
+    const int idx = tid + 256 * u;
     const int pr = idx / PC, pc = idx - pr * PC;
     const int hi = 2 * oy0 - 3 + pr, wi = 2 * ox0 - 3 + pc;
     u32x2 v = {0u, 0u};
-    if (hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win)
+    if (tile < a.total_tiles && idx < PR * PC && hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win)
       v = *reinterpret_cast<const u32x2*>(a.in + (((size_t)n * a.Hin + hi) * a.Win + wi) * 4);
-    *reinterpret_cast<u32x2*>(Ps + pr * PROW + pc * 8) = v;
+    r[u] = v;
+  }
+}
+__device__ __forceinline__ void commit_patch(unsigned char* Ps, const u32x2 (&r)[PATCH_PER_THREAD], int tid) {
+#pragma unroll
+  for (int u = 0; u < PATCH_PER_THREAD; ++u) {
+    const int idx = tid + 256 * u;
+    if (idx < PR * PC) {
+      const int pr = idx / PC, pc = idx - pr * PC;
+      *reinterpret_cast<u32x2*>(Ps + pr * PROW + pc * 8) = r[u];
+    }
   }
 }
 
@@ -59,13 +77,16 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(StemArgs a) {
     *reinterpret_cast<u32x4*>(Ws + co * WROW + ch * 16) = *reinterpret_cast<const u32x4*>(a.w + co * 224 + ch * 8);
   }
 
+  u32x2 pre[PATCH_PER_THREAD];
+  fetch_patch(pre, a, blockIdx.x, tid);
   for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
     const int n = tile / (a.tiles_h * a.tiles_w);
     const int t2 = tile - n * (a.tiles_h * a.tiles_w);
     const int oy0 = (t2 / a.tiles_w) * TH, ox0 = (t2 % a.tiles_w) * TW;
-    __syncthreads();  // previous tile's epilogue reads done / weights visible
-    load_patch(Ps, a, n, oy0, ox0, tid);
+    lds_barrier();    // previous tile's patch and C tile fully consumed / weights visible (no wait for its stores)
+    commit_patch(Ps, pre, tid);
     __syncthreads();
+    fetch_patch(pre, a, tile + gridDim.x, tid);          // next tile's loads fly under this tile's MFMAs and stores
 
     f32x4 acc[2][4];
 #pragma unroll
@@ -83,29 +104,31 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(StemArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         bfr[j] = *reinterpret_cast<const bf16x8*>(Ws + (j * 16 + fi) * WROW + kh * 64 + fg * 16);
+      // swapped operand roles, D[co][pixel]: lane (fg, fi) ends with output channels 16j + 4fg + {0..3} of pixel fi
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
-    // epilogue through LDS: pixel index p = oyl*16 + oxl, row-major [p][co]
+    // epilogue through LDS: pixel index p = oyl*16 + oxl, row-major [p][co]; one packed 8-byte store per MFMA tile
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int p = (wave * 2 + i) * 16 + fg * 4 + r;
-          Cs[p * CPAD + j * 16 + fi] = f32_to_bf16_bits(acc[i][j][r]);
-        }
-    __syncthreads();
+      for (int j = 0; j < 4; ++j) {
+        const int p = (wave * 2 + i) * 16 + fi;
+        u32x2 v;
+        v[0] = (unsigned)f32_to_bf16_bits(acc[i][j][0]) | ((unsigned)f32_to_bf16_bits(acc[i][j][1]) << 16);
+        v[1] = (unsigned)f32_to_bf16_bits(acc[i][j][2]) | ((unsigned)f32_to_bf16_bits(acc[i][j][3]) << 16);
+        *reinterpret_cast<u32x2*>(Cs + p * CPAD + j * 16 + fg * 4) = v;
+      }
+    lds_barrier();
     for (int idx = tid; idx < TH * TW * 8; idx += 256) {
       const int p = idx >> 3, ch = idx & 7;
       const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
       if (oy < a.Hout && ox < a.Wout)
-        *reinterpret_cast<u32x4*>(a.out + (((size_t)n * a.Hout + oy) * a.Wout + ox) * 64 + ch * 8) =
-            *reinterpret_cast<const u32x4*>(Cs + p * CPAD + ch * 8);
+        __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(Cs + p * CPAD + ch * 8),
+                                    reinterpret_cast<u32x4*>(a.out + (((size_t)n * a.Hout + oy) * a.Wout + ox) * 64 + ch * 8));
     }
   }
 }
@@ -125,21 +148,37 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(StemArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+  // operands of the next tile are fetched into registers while the current one is multiplied
+  u32x2 pre[PATCH_PER_THREAD];
+  u32x4 prey[4];
+  auto fetch_dy = [&](int tile) {
     const int n = tile / (a.tiles_h * a.tiles_w);
     const int t2 = tile - n * (a.tiles_h * a.tiles_w);
     const int oy0 = (t2 / a.tiles_w) * TH, ox0 = (t2 % a.tiles_w) * TW;
-    __syncthreads();
-    load_patch(Ps, a, n, oy0, ox0, tid);
-    for (int idx = tid; idx < TH * TW * 8; idx += 256) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + 256 * u;
       const int p = idx >> 3, ch = idx & 7;
       const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (oy < a.Hout && ox < a.Wout)
+      if (tile < a.total_tiles && oy < a.Hout && ox < a.Wout)
         v = *reinterpret_cast<const u32x4*>(a.dy + (((size_t)n * a.Hout + oy) * a.Wout + ox) * 64 + ch * 8);
-      *reinterpret_cast<u32x4*>(Ys + p * YROW + ch * 16) = v;
+      prey[u] = v;
     }
-    __syncthreads();
+  };
+  fetch_patch(pre, a, blockIdx.x, tid);
+  fetch_dy(blockIdx.x);
+  for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+    lds_barrier();                                       // previous tile's operands fully consumed
+    commit_patch(Ps, pre, tid);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + 256 * u;
+      *reinterpret_cast<u32x4*>(Ys + (idx >> 3) * YROW + (idx & 7) * 16) = prey[u];
+    }
+    lds_barrier();
+    fetch_patch(pre, a, tile + gridDim.x, tid);
+    fetch_dy(tile + gridDim.x);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int k1 = ks * 32 + 8 * fg + fq, k2 = k1 + 4;   // the two pixel rows this lane addresses
