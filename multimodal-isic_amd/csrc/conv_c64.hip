@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(C64Args a) {
     const int row = idx >> 3, ch = idx & 7;
     const long long pix = pix_index(row);
     if (pix >= 0)
-      *reinterpret_cast<u32x4*>(a.out + pix * 64 + ch * 8) = *reinterpret_cast<const u32x4*>(Cs + row * CPAD + ch * 8);
+      __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(Cs + row * CPAD + ch * 8),
+                                  reinterpret_cast<u32x4*>(a.out + pix * 64 + ch * 8));
   }
   C64_STAMP(3);
 }
@@ -282,10 +283,10 @@ __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsig
 // (the s_nop covers the hazard "VMEM store of more than 64 bits followed by a write of its data VGPRs", which the
 //  compiler cannot see through the asm statement)
 __device__ __forceinline__ void store16_s(void* sbase, unsigned voff, u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void store16_v(void* ptr, u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
 }
 
 template <bool STATS, bool ADDEND>

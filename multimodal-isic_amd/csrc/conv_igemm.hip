@@ -367,7 +367,7 @@ __global__ __launch_bounds__((MODE >= 4 ? 2 : 1) * WAVES_M * WAVES_N * 64, MODE 
     if (m < a.M) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(Cs + row * CPAD + ch * 8);
       const size_t pix = dense ? (size_t)m : out_index(m);
-      *reinterpret_cast<u32x4*>(a.out + pix * a.Cout + n0 + ch * 8) = v;
+      __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.out + pix * a.Cout + n0 + ch * 8));   // streaming: not re-read here
     }
   }
 }
