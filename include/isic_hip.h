@@ -238,6 +238,11 @@ int isic_conv_weight_prep_bf16(const float* w_krsc, uint16_t* w_fwd, uint16_t* w
  * fp32 [64][7][7][3]. */
 int isic_conv_stem_fwd_bf16(const uint16_t* in_nhwc4, const uint16_t* w_stem, uint16_t* out, int N, int Hin, int Win,
                             int Hout, int Wout, void* stream);
+/* ... with the BatchNorm statistics of the (rounded) output fused, as isic_conv2d_igemm_bf16 does:
+ * stat_sum / stat_sumsq [stat_slots][64] fp64, accumulated into (zero them first). */
+int isic_conv_stem_fwd_stats_bf16(const uint16_t* in_nhwc4, const uint16_t* w_stem, uint16_t* out, int N, int Hin,
+                                  int Win, int Hout, int Wout, double* stat_sum, double* stat_sumsq, int stat_slots,
+                                  void* stream);
 int isic_conv_stem_wgrad_bf16(const uint16_t* in_nhwc4, const uint16_t* dy, float* dw, int N, int Hin, int Win,
                               int Hout, int Wout, void* stream);
 int isic_conv_stem_pack_bf16(const float* w_krsc, uint16_t* w_stem, void* stream);

@@ -30,6 +30,9 @@ struct StemArgs {
   unsigned short* out;        // [N,Hout,Wout,64]
   const unsigned short* dy;   // wgrad: [N,Hout,Wout,64]
   float* dw;                  // wgrad: [64][7][7][3] fp32
+  double* stat_sum;           // fwd, optional: [slots][64] BatchNorm sum / sum of squares of the rounded outputs
+  double* stat_sumsq;
+  int stat_slots;
   int N, Hin, Win, Hout, Wout, tiles_h, tiles_w, total_tiles;
 };
 
@@ -79,6 +82,7 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(StemArgs a) {
 
   u32x2 pre[PATCH_PER_THREAD];
   fetch_patch(pre, a, blockIdx.x, tid);
+  double st_s = 0.0, st_q = 0.0;          // fused BatchNorm statistics: thread = (channel tid & 63, pixel quarter tid >> 6)
   for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
     const int n = tile / (a.tiles_h * a.tiles_w);
     const int t2 = tile - n * (a.tiles_h * a.tiles_w);
@@ -123,6 +127,17 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(StemArgs a) {
         *reinterpret_cast<u32x2*>(Cs + p * CPAD + j * 16 + fg * 4) = v;
       }
     lds_barrier();
+    if (a.stat_sum) {                                    // fp32 over the 32 pixels of this tile, fp64 across tiles
+      const int c = tid & 63, q = tid >> 6;
+      float s = 0.f, sq = 0.f;
+#pragma unroll 8
+      for (int p = q * 32; p < q * 32 + 32; ++p) {
+        const float v = bf16_bits_to_f32(Cs[p * CPAD + c]);
+        const bool in = (oy0 + (p >> 4) < a.Hout) && (ox0 + (p & 15) < a.Wout);
+        s += in ? v : 0.f; sq += in ? v * v : 0.f;
+      }
+      st_s += (double)s; st_q += (double)sq;
+    }
     for (int idx = tid; idx < TH * TW * 8; idx += 256) {
       const int p = idx >> 3, ch = idx & 7;
       const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
@@ -130,6 +145,11 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(StemArgs a) {
         __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(Cs + p * CPAD + ch * 8),
                                     reinterpret_cast<u32x4*>(a.out + (((size_t)n * a.Hout + oy) * a.Wout + ox) * 64 + ch * 8));
     }
+  }
+  if (a.stat_sum) {
+    const size_t slot = (size_t)(blockIdx.x % a.stat_slots) * 64 + (tid & 63);
+    atomicAdd(a.stat_sum + slot, st_s);
+    atomicAdd(a.stat_sumsq + slot, st_q);
   }
 }
 
@@ -253,8 +273,17 @@ extern "C" {
 
 int isic_conv_stem_fwd_bf16(const uint16_t* in_nhwc4, const uint16_t* w_stem, uint16_t* out, int N, int Hin, int Win,
                             int Hout, int Wout, void* stream) {
+  return isic_conv_stem_fwd_stats_bf16(in_nhwc4, w_stem, out, N, Hin, Win, Hout, Wout, nullptr, nullptr, 0, stream);
+}
+
+int isic_conv_stem_fwd_stats_bf16(const uint16_t* in_nhwc4, const uint16_t* w_stem, uint16_t* out, int N, int Hin,
+                                  int Win, int Hout, int Wout, double* stat_sum, double* stat_sumsq, int stat_slots,
+                                  void* stream) {
   ISIC_CHECK_ARG(in_nhwc4 && w_stem && out && N > 0 && Hin > 0 && Win > 0);
+  ISIC_CHECK_ARG((stat_sum == nullptr) == (stat_sumsq == nullptr));
+  ISIC_CHECK_ARG(!stat_sum || stat_slots > 0);
   StemArgs a;
+  a.stat_sum = stat_sum; a.stat_sumsq = stat_sumsq; a.stat_slots = stat_slots > 0 ? stat_slots : 1;
   a.in = in_nhwc4; a.w = w_stem; a.out = out; a.dy = nullptr; a.dw = nullptr;
   int rc = stem_args(a, N, Hin, Win, Hout, Wout);
   if (rc != ISIC_OK) return rc;
@@ -267,6 +296,7 @@ int isic_conv_stem_wgrad_bf16(const uint16_t* in_nhwc4, const uint16_t* dy, floa
                               int Hout, int Wout, void* stream) {
   ISIC_CHECK_ARG(in_nhwc4 && dy && dw && N > 0 && Hin > 0 && Win > 0);
   StemArgs a;
+  a.stat_sum = nullptr; a.stat_sumsq = nullptr; a.stat_slots = 1;
   a.in = in_nhwc4; a.w = nullptr; a.out = nullptr; a.dy = dy; a.dw = dw;
   int rc = stem_args(a, N, Hin, Win, Hout, Wout);
   if (rc != ISIC_OK) return rc;

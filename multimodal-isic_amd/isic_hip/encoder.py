@@ -306,10 +306,15 @@ class ResNet18Encoder(nn.Module):
         Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         ws, _ = self._weights("conv1", False)
         c = _empty((N, Ho, Wo, 64), x0)
-        call("isic_conv_stem_fwd_bf16", x0, ws, c, N, H, W, Ho, Wo)
+        acc0 = None
+        if self.training:      # batch statistics of bn1 fused into the stem convolution's epilogue
+            acc0 = torch.zeros(2, STAT_SLOTS, 64, device=x0.device, dtype=torch.float64)
+            call("isic_conv_stem_fwd_stats_bf16", x0, ws, c, N, H, W, Ho, Wo, acc0[0], acc0[1], STAT_SLOTS)
+        else:
+            call("isic_conv_stem_fwd_bf16", x0, ws, c, N, H, W, Ho, Wo)
         # bn1 + relu + maxpool in one pass over the stem activation (the largest tensor of the network): the
         # normalised tensor is never written; backward recomputes the ReLU mask from c
-        st0 = self._bn_affine(c, "bn1")
+        st0 = self._bn_affine(c, "bn1", acc0)
         Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
         p = _empty((N, Hp, Wp, 64), c)
         am = torch.empty((N, Hp, Wp, 64), device=c.device, dtype=torch.uint8) if save else None

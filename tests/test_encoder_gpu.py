@@ -248,6 +248,14 @@ def test_stem_forward_and_wgrad(shape):
     out = torch.empty(N, Ho, Wo, 64, device=DEV, dtype=BF)
     call("isic_conv_stem_fwd_bf16", x4, ws, out, N, H, W, Ho, Wo)
     bf16_close(from_nhwc(out), y.detach(), f"stem fwd {shape}")
+    # fused BatchNorm statistics == statistics of the rounded output
+    out2 = torch.empty_like(out)
+    st = torch.zeros(2, 32, 64, device=DEV, dtype=torch.float64)
+    call("isic_conv_stem_fwd_stats_bf16", x4, ws, out2, N, H, W, Ho, Wo, st[0], st[1], 32)
+    assert torch.equal(out2.view(torch.int16), out.view(torch.int16))
+    o = out.float().reshape(-1, 64).double()
+    assert_close(st[0].sum(0), o.sum(0), rtol=1e-5, atol=1e-4, what="stem fused sum")
+    assert_close(st[1].sum(0), (o * o).sum(0), rtol=1e-5, atol=1e-4, what="stem fused sumsq")
     dw = torch.zeros(64, 3, 7, 7, device=DEV).contiguous(memory_format=torch.channels_last)
     call("isic_conv_stem_wgrad_bf16", x4, nhwc(dy), dw, N, H, W, Ho, Wo)
     assert_close(dw.cpu(), w.grad, rtol=2e-4, atol=1e-5, what=f"stem wgrad {shape}")
