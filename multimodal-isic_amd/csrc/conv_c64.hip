@@ -383,7 +383,6 @@ __global__ __launch_bounds__(512) void conv3x3_c64p_kernel(C64PArgs a) {
   const unsigned lane_out = (unsigned)(fr * 64 + co0) * 2;               // byte offset inside an output row segment
 
   f32x4 acc[4][2];
-  u32x4 ad[4];
   float s8[8], q8[8];                                   // per-lane BatchNorm partial sums over ALL tiles of the block
 #pragma unroll
   for (int c = 0; c < 8; ++c) { s8[c] = 0.f; q8[c] = 0.f; }
@@ -400,10 +399,23 @@ __global__ __launch_bounds__(512) void conv3x3_c64p_kernel(C64PArgs a) {
     return c0 + 15 < a.W ? 0 : 2;
   };
 
-  // ---- register-only epilogue of tile t
-  // (the addend registers come from ordinary loads: the compiler waits for them with its own vmcnt, which can only
-  //  be stricter than needed -- it also drains the patch DMA issued behind them, one tile of MFMAs earlier)
+  // ---- register-only epilogue of tile t.  The addend (16 bytes per M-tile) is loaded HERE, where the operand fragment
+  // registers are dead, with ordinary loads: the compiler waits for them with its own vmcnt, which can only be
+  // stricter than needed (it also drains the patch DMA issued before them, one tile of MFMAs earlier); the latency
+  // is covered by the other wave of the SIMD, which is half a tile away.
   auto epilogue = [&](const Tile& tl) {
+    u32x4 ad[4];
+    if (ADDEND) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {            // unconditional: exactly 4 loads per tile (see CNT_TOP)
+        size_t off;
+        const int seg = segment(tl, i, off);
+        const bool valid = seg == 0 || (seg == 2 && tl.x0 + (i & 1) * 16 + fr < a.W);
+        const unsigned char* ap = valid ? reinterpret_cast<const unsigned char*>(a.addend + off) + lane_out
+                                        : g_c64_zeros + lane * 16;
+        ad[i] = *reinterpret_cast<const u32x4*>(ap);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       size_t off;
@@ -439,13 +451,13 @@ __global__ __launch_bounds__(512) void conv3x3_c64p_kernel(C64PArgs a) {
     }
   };
 
-  // In-flight vector memory operations YOUNGER than the patch DMA of tile kk when iteration kk starts.  The waves of
-  // channel half 0 run  [addend loads kk, DMA kk+2, MFMAs kk, stores kk]  per iteration, those of half 1 DEFER the
-  // epilogue behind the next barrier --  [stores kk-1, addend loads kk, DMA kk+2, MFMAs kk]  -- so that on every SIMD
-  // one wave's epilogue runs under the other wave's MFMAs.
-  constexpr int NADD = ADDEND ? 4 : 0;
-  constexpr int CNT_TOP0 = 4 + NADD + P_DMA + 4;        // stores(kk-2), addend(kk-1), DMA(kk+1), stores(kk-1)
-  constexpr int CNT_TOP1 = 4 + NADD + P_DMA;            // stores(kk-2), addend(kk-1), DMA(kk+1)
+  // In-flight vector memory operations YOUNGER than the patch DMA of tile kk (issued among the MFMAs of iteration kk-2)
+  // when iteration kk starts.  The waves of channel half 0 run  [DMA kk+2 + MFMAs kk, addend loads kk, stores kk]  per
+  // iteration, those of half 1 DEFER the epilogue behind the next barrier --  [addend loads kk-1, stores kk-1,
+  // DMA kk+2 + MFMAs kk]  -- so that on every SIMD one wave's epilogue runs under the other wave's MFMAs.
+  constexpr int NEPI = 4 + (ADDEND ? 4 : 0);            // memory operations of one epilogue
+  constexpr int CNT_TOP0 = NEPI + P_DMA + NEPI;         // epilogue(kk-2), DMA(kk+1), epilogue(kk-1)
+  constexpr int CNT_TOP1 = NEPI + P_DMA;                // epilogue(kk-2), DMA(kk+1)
   if (STATS) lds_barrier();                             // statistics slots zeroed
 
   Tile prev = cur;
@@ -458,18 +470,6 @@ __global__ __launch_bounds__(512) void conv3x3_c64p_kernel(C64PArgs a) {
     C64P_STAMP(kk, 1);
 
     if (half == 1 && kk > 0) epilogue(prev);
-    if (ADDEND) {
-      const Tile& tl = cur;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {            // unconditional: exactly 4 loads per tile (see CNT_TOP)
-        size_t off;
-        const int seg = segment(tl, i, off);
-        const bool valid = seg == 0 || (seg == 2 && tl.x0 + (i & 1) * 16 + fr < a.W);
-        const unsigned char* ap = valid ? reinterpret_cast<const unsigned char*>(a.addend + off) + lane_out
-                                        : g_c64_zeros + lane * 16;
-        ad[i] = *reinterpret_cast<const u32x4*>(ap);
-      }
-    }
     const bool more = kk + 2 < ntl;
     const int buf_ahead = (kk + 2) % P_NBUF;
 
@@ -545,7 +545,7 @@ int isic_conv3x3_c64_launch(int variant, const uint16_t* in, const uint16_t* w, 
   const int tiles_y = ceil_div(H, TH), tiles_x = ceil_div(W, TW);
   const int64_t blocks = (int64_t)N * tiles_y * tiles_x;
   if (blocks > 0x7FFFFFFFLL) return ISIC_ERR_UNSUPPORTED;
-  if (variant == 2 && !addend) {   // (the addend form of the persistent kernel does not fit the register file)
+  if (variant == 2 && !(stat_sum && addend)) {
     static int cus = 0;
     if (cus == 0) {
       int dev = 0;
@@ -561,6 +561,7 @@ int isic_conv3x3_c64_launch(int variant, const uint16_t* in, const uint16_t* w, 
     a.tiles_per_block = ceil_div(a.total_tiles, cus);
     const int grid = ceil_div(a.total_tiles, a.tiles_per_block);       // every block owns at least one tile
     if (stat_sum) return launch_c64p<true, false>(a, grid, stream);
+    if (addend) return launch_c64p<false, true>(a, grid, stream);
     return launch_c64p<false, false>(a, grid, stream);
   }
   C64Args a;
