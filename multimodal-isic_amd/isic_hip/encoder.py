@@ -81,6 +81,8 @@ class ResNet18Encoder(nn.Module):
                 inp = planes
         self._wcache = {}      # conv name -> (w_fwd bf16, w_dgrad bf16)
         self._wgrad_ws = None
+        self._zeros = None            # fp64 arena for the per-layer statistics accumulators: ONE memset per pass
+        self._zeros_used = 0
         self._side = None             # second HIP stream: weight gradients run beside the data-gradient chain
         self.grad_ready_hook = None   # callable(list_of_param_names) fired as gradients complete (DDP overlap)
 
@@ -151,7 +153,7 @@ class ResNet18Encoder(nn.Module):
         out = _empty((N, Ho, Wo, sp.cout), x)
         acc = None
         if with_stats and self.training:
-            acc = torch.zeros(2, STAT_SLOTS, sp.cout, device=x.device, dtype=torch.float64)
+            acc = self._zeros64((2, STAT_SLOTS, sp.cout), x.device)
         call("isic_conv2d_igemm_bf16", x, wf, out, N, H, W, C, Ho, Wo, sp.cout, sp.k, sp.k, sp.stride, 1, sp.pad, None,
              acc[0] if acc is not None else None, acc[1] if acc is not None else None, STAT_SLOTS)
         return out, acc
@@ -171,6 +173,25 @@ class ResNet18Encoder(nn.Module):
         if p.grad is None:
             p.grad = torch.zeros_like(p.data, memory_format=torch.preserve_format)
         return p.grad
+
+    _ARENA_DOUBLES = 2 * STAT_SLOTS * 4800 + 2 * 64 * STAT_SLOTS + 4096     # all conv / BN layers of ResNet-18, one pass
+
+    def _arena_reset(self, device):
+        """Zero the statistics arena (one fill kernel instead of one torch.zeros per layer)."""
+        if self._zeros is None or self._zeros.device != device:
+            self._zeros = torch.empty(self._ARENA_DOUBLES, device=device, dtype=torch.float64)
+        self._zeros.zero_()
+        self._zeros_used = 0
+
+    def _zeros64(self, shape, device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if self._zeros is None or self._zeros.device != device or self._zeros_used + n > self._zeros.numel():
+            return torch.zeros(shape, device=device, dtype=torch.float64)   # outside a pass / arena exhausted
+        v = self._zeros[self._zeros_used:self._zeros_used + n].view(shape)
+        self._zeros_used += n
+        return v
 
     def _side_stream(self, device):
         """Weight gradients are leaves of the backward graph: with ISIC_WGRAD_STREAM=1 they run on a second
@@ -239,7 +260,7 @@ class ResNet18Encoder(nn.Module):
             slots = STAT_SLOTS
             if acc is None:
                 slots = 1
-                acc = torch.zeros(2, 1, C, device=dev, dtype=torch.float64)
+                acc = self._zeros64((2, 1, C), dev)
                 call("isic_bn_stats_bf16", c, rows, C, acc[0], acc[1])
             mean = torch.empty(C, device=dev, dtype=torch.float32)
             rstd = torch.empty(C, device=dev, dtype=torch.float32)
@@ -258,7 +279,7 @@ class ResNet18Encoder(nn.Module):
         N, H, W, C = c.shape
         rows = N * H * W
         gamma, beta = self._get(name + ".weight"), self._get(name + ".bias")
-        acc = torch.zeros(2, C, device=c.device, dtype=torch.float64)
+        acc = self._zeros64((2, C), c.device)
         if mask is not None and relu and not mask_from_x:
             call("isic_bn_bwd_reduce_mask_bf16", dy, c, mask, mean, rstd, rows, C, acc[0], acc[1])
             dx = _empty(c.shape, c)
@@ -302,13 +323,14 @@ class ResNet18Encoder(nn.Module):
         needed (inference)."""
         self.prepare_weights()
         x0 = self.pack_input(images)
+        self._arena_reset(x0.device)
         N, H, W, _ = x0.shape
         Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         ws, _ = self._weights("conv1", False)
         c = _empty((N, Ho, Wo, 64), x0)
         acc0 = None
         if self.training:      # batch statistics of bn1 fused into the stem convolution's epilogue
-            acc0 = torch.zeros(2, STAT_SLOTS, 64, device=x0.device, dtype=torch.float64)
+            acc0 = self._zeros64((2, STAT_SLOTS, 64), x0.device)
             call("isic_conv_stem_fwd_stats_bf16", x0, ws, c, N, H, W, Ho, Wo, acc0[0], acc0[1], STAT_SLOTS)
         else:
             call("isic_conv_stem_fwd_bf16", x0, ws, c, N, H, W, Ho, Wo)
@@ -354,6 +376,7 @@ class ResNet18Encoder(nn.Module):
         if not self.training:
             raise IsicHipError("encoder backward needs train() mode (batch-statistics BatchNorm)")
         N, Hf, Wf, Cf = tape["final_shape"]
+        self._arena_reset(dfeat.device)
         g = torch.empty((N, Hf, Wf, Cf), device=dfeat.device, dtype=_BF16)
         call("isic_avgpool_bwd_bf16", dfeat.float().contiguous(), g, N, Hf * Wf, Cf)
         for (pre, ds), saved in zip(reversed(self.blocks), reversed(tape["blocks"])):
@@ -384,7 +407,7 @@ class ResNet18Encoder(nn.Module):
         # max-pool backward gathered inside the BatchNorm backward passes: no full-size gradient tensor
         mean, rstd, scale, shift = st0
         gamma, beta = self._get("bn1.weight"), self._get("bn1.bias")
-        acc = torch.zeros(2, 64, device=c.device, dtype=torch.float64)
+        acc = self._zeros64((2, 64), c.device)
         call("isic_bn_bwd_reduce_pooled_bf16", am, g, c, mean, rstd, N, Ho, Wo, 64, Hp, Wp, scale, shift, acc[0], acc[1])
         dc = _empty(c.shape, c)
         call("isic_bn_bwd_apply_pooled_bf16", am, g, c, mean, rstd, gamma.data, acc[0], acc[1], N, Ho, Wo, 64, Hp, Wp,
