@@ -59,6 +59,12 @@ struct ConvArgs {
   unsigned long long magic_hw, magic_w;   // floor(2^40/d)+1 for d = Hs*Ws and d = Ws (M < 2^24)
 };
 
+// the (up to four) output-parity classes of a strided data gradient run as ONE launch: blockIdx.z picks the class
+struct ConvArgsN {
+  ConvArgs c[4];
+  int n;
+};
+
 __device__ __forceinline__ unsigned fastdiv40(unsigned n, unsigned long long magic) {
   return (unsigned)(((unsigned long long)n * magic) >> 40);
 }
@@ -89,7 +95,9 @@ __device__ unsigned long long g_igemm_stamps[256 * 40 * 8];
 #endif
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE>
-__global__ __launch_bounds__((MODE >= 4 ? 2 : 1) * WAVES_M * WAVES_N * 64, MODE >= 4 ? 4 : 1) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__((MODE >= 4 ? 2 : 1) * WAVES_M * WAVES_N * 64, MODE >= 4 ? 4 : 1) void conv_igemm_kernel(ConvArgsN classes) {
+  const ConvArgs a = classes.c[blockIdx.z];           // by value: loaded into scalar registers once
+  if ((int)(blockIdx.x * BM) >= a.M) return;            // this class has fewer row tiles than the largest one (whole block)
   constexpr bool DB = (MODE == 1);
   constexpr bool GLDS = (MODE >= 2);
   constexpr int NSTAGE = (MODE == 3 || MODE == 5) ? 3 : (MODE == 0 ? 1 : 2);
@@ -390,7 +398,7 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, unsigned short* 
 }
 
 template <int BM, int BN, int WM, int WN, int MODE>
-int launch_conv(const ConvArgs& a, hipStream_t s) {
+int launch_conv(const ConvArgsN& a, hipStream_t s) {
   constexpr int STAGE = (BM + BN) * BK * 2;
   constexpr int MT = WM * WN * 64;
   constexpr int CBYTES = BM * (BN + 8) * 2 + 2 * MT * 4;
@@ -404,13 +412,15 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
       return ISIC_ERR_LAUNCH;
     attr_done = true;
   }
-  dim3 grid(ceil_div(a.M, BM), a.Cout / BN);
+  int maxM = 0;
+  for (int i = 0; i < a.n; ++i) maxM = a.c[i].M > maxM ? a.c[i].M : maxM;
+  dim3 grid(ceil_div(maxM, BM), a.c[0].Cout / BN, a.n);
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MODE>), grid, dim3(THREADS), LDS, s, a);
   return ISIC_OK;
 }
 
 template <int BM, int BN, int WM, int WN>
-int launch_conv_mode(int mode, const ConvArgs& a, hipStream_t s) {
+int launch_conv_mode(int mode, const ConvArgsN& a, hipStream_t s) {
   switch (mode) {
     case 1: return launch_conv<BM, BN, WM, WN, 1>(a, s);
     case 2: return launch_conv<BM, BN, WM, WN, 2>(a, s);
@@ -473,7 +483,9 @@ int isic_conv2d_igemm_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out,
   a.Kh = Kh; a.Kw = Kw; a.up = up; a.down_shift = down == 1 ? 0 : 1; a.pad = pad;
   a.ctiles = Cin / 64;
   hipStream_t s = as_stream(stream);
-  // parity classes of the output grid (1 class for down == 1)
+  // parity classes of the output grid (1 class for down == 1): all of them in one launch
+  ConvArgsN all;
+  all.n = 0;
   for (int ph = 0; ph < down; ++ph)
     for (int pw = 0; pw < down; ++pw) {
       a.ostep = down; a.oh0 = ph; a.ow0 = pw;
@@ -492,13 +504,17 @@ int isic_conv2d_igemm_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out,
       a.Ktiles = a.nkh * a.nkw * a.ctiles;
       // a class without any tap still has to write (addend or zeros): Ktiles == 0 is handled by the kernel
       if (a.nkh > 16 || a.nkw > 16) return ISIC_ERR_UNSUPPORTED;   // per-row tap validity lives in 2 x 16+ bits
-      int rc;
-      const int mode = conv_mode();
-      if (Cout % 128 != 0) rc = launch_conv_mode<256, 64, 4, 1>(mode == 5 ? 4 : mode, a, s);
-      else if (mode == 5) rc = launch_conv<256, 128, 4, 2, 5>(a, s);        // 8 MFMA + 8 staging waves, three stages
-      else rc = launch_conv_mode<128, 128, 2, 2>(mode, a, s);
-      if (rc != ISIC_OK) return rc;
+      all.c[all.n++] = a;
     }
+  if (all.n == 0) return ISIC_OK;
+  {
+    int rc;
+    const int mode = conv_mode();
+    if (Cout % 128 != 0) rc = launch_conv_mode<256, 64, 4, 1>(mode == 5 ? 4 : mode, all, s);
+    else if (mode == 5) rc = launch_conv<256, 128, 4, 2, 5>(all, s);        // 8 MFMA + 8 staging waves, three stages
+    else rc = launch_conv_mode<128, 128, 2, 2>(mode, all, s);
+    if (rc != ISIC_OK) return rc;
+  }
   return isic_launch_status();
 }
 
