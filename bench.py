@@ -158,8 +158,11 @@ def main():
     torch.cuda.synchronize()
     timer.active = True
     t0 = time.perf_counter()
+    host_s = 0.0
     for i in range(args.steps):
+        th = time.perf_counter()
         loss = step(2 + args.warmup + i)
+        host_s += time.perf_counter() - th          # host time to ENQUEUE the step (the GPU runs behind it)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -190,7 +193,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": WORKLOAD, "bags_per_step_per_gpu": B, "global_bags_per_step": B * world,
                        "patches_per_bag": K, "patch": f"3x{S}x{S}", "radiomics_dim": R,
-                       "parallelism": f"dp{world}", "final_loss": final_loss},
+                       "parallelism": f"dp{world}", "host_enqueue_ms_per_step": host_s * 1e3 / args.steps, "final_loss": final_loss},
             "roofline": {
                 "bound": "mfma", "kernel": "conv_igemm_kernel (isic_conv2d_igemm_bf16: forward + data-gradient)",
                 "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
