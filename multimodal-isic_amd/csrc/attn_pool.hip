@@ -240,6 +240,9 @@ struct PoolBwdArgs {
 };
 
 // LDS (floats): w3s[heads*A] | W4s[C*H] | dzs[H] | da[max_bag*heads] | red[NWAVE*heads]
+// FAST: H <= 128 and A <= 128 -- the h / attention-hidden values of a row are fetched up front (two per lane and head)
+// instead of through runtime-length loops of dependent loads (as attn_pool_fwd_kernel<JH, 2>)
+template <bool FAST>
 __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(PoolBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = a.H, A = a.A, NH = a.heads, C = a.C;
@@ -272,7 +275,12 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(PoolBwdArgs a) {
     if (a.d_z) {
       const float* hrow = a.h + (size_t)(lo + n) * H;
       float p = 0.f;
-      for (int j = lane; j < H; j += 64) p += hrow[j] * dzs[j];
+      if (FAST) {
+        const float h0 = lane < H ? hrow[lane] : 0.f, h1 = lane + 64 < H ? hrow[lane + 64] : 0.f;
+        p = (lane < H ? h0 * dzs[lane] : 0.f) + (lane + 64 < H ? h1 * dzs[lane + 64] : 0.f);
+      } else {
+        for (int j = lane; j < H; j += 64) p += hrow[j] * dzs[j];
+      }
       base = wave_sum(p) * inv_heads;
     }
     float cls = 0.f;
@@ -315,11 +323,29 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(PoolBwdArgs a) {
     if (a.d_u) {
       const float* trow = a.t + (size_t)(lo + n) * At;
       float* urow = a.d_u + (size_t)(lo + n) * At;
+      if (FAST) {
+        float tv[MAX_HEADS][2];
 #pragma unroll
-      for (int k = 0; k < MAX_HEADS; ++k) if (k < NH) {
-        for (int j = lane; j < A; j += 64) {
-          const float tv = trow[k * A + j];
-          urow[k * A + j] = ds[k] * w3s[k * A + j] * (1.f - tv * tv);
+        for (int k = 0; k < MAX_HEADS; ++k)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int j = lane + 64 * i;
+            tv[k][i] = (k < NH && j < A) ? trow[k * A + j] : 0.f;
+          }
+#pragma unroll
+        for (int k = 0; k < MAX_HEADS; ++k)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int j = lane + 64 * i;
+            if (k < NH && j < A) urow[k * A + j] = ds[k] * w3s[k * A + j] * (1.f - tv[k][i] * tv[k][i]);
+          }
+      } else {
+#pragma unroll
+        for (int k = 0; k < MAX_HEADS; ++k) if (k < NH) {
+          for (int j = lane; j < A; j += 64) {
+            const float tv = trow[k * A + j];
+            urow[k * A + j] = ds[k] * w3s[k * A + j] * (1.f - tv * tv);
+          }
         }
       }
     }
@@ -414,9 +440,16 @@ int isic_attn_pool_bwd(const float* h, const float* t, const float* att, const f
   a.d_u = d_u; a.d_s = d_s; a.d_P = d_P;
   const size_t lds = sizeof(float) * ((size_t)heads * A + (W4 ? (size_t)C * H : 0) + H + (size_t)max_bag * heads +
                                       NWAVE * heads);
-  int rc = ensure_lds(attn_pool_bwd_kernel, lds);
-  if (rc != ISIC_OK) return rc;
-  hipLaunchKernelGGL(attn_pool_bwd_kernel, dim3(B), dim3(256), lds, as_stream(stream), a);
+  int rc;
+  if (H <= 128 && A <= 128) {
+    rc = ensure_lds(attn_pool_bwd_kernel<true>, lds);
+    if (rc != ISIC_OK) return rc;
+    hipLaunchKernelGGL(attn_pool_bwd_kernel<true>, dim3(B), dim3(256), lds, as_stream(stream), a);
+  } else {
+    rc = ensure_lds(attn_pool_bwd_kernel<false>, lds);
+    if (rc != ISIC_OK) return rc;
+    hipLaunchKernelGGL(attn_pool_bwd_kernel<false>, dim3(B), dim3(256), lds, as_stream(stream), a);
+  }
   return isic_launch_status();
 }
 
