@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const unsigned short* __r
 #pragma unroll 4
   for (int64_t r = (int64_t)blockIdx.x * rls + rl; r < rows; r += (int64_t)gridDim.x * rls) {
     float f[8];
-    unpack8(*reinterpret_cast<const u32x4*>(x + r * C + cg * 8), f);
+    unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(x + r * C + cg * 8)), f);
 #pragma unroll
     for (int j = 0; j < 8; ++j) { acc[0][j] += f[j]; acc[1][j] += f[j] * f[j]; }
   }
@@ -189,8 +189,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned short
 #pragma unroll 2
   for (int64_t r = (int64_t)blockIdx.x * rls + rl; r < rows; r += (int64_t)gridDim.x * rls) {
     float g[8], xv[8], yv[8];
-    unpack8(*reinterpret_cast<const u32x4*>(dy + r * C + cg * 8), g);
-    unpack8(*reinterpret_cast<const u32x4*>(x + r * C + cg * 8), xv);
+    unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dy + r * C + cg * 8)), g);
+    unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(x + r * C + cg * 8)), xv);
     if (from_x) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) yv[j] = xv[j] * sc[j] + sh[j];
@@ -243,8 +243,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 #pragma unroll 2
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
     float g[8], xv[8], yv[8], o[8];
-    unpack8(*reinterpret_cast<const u32x4*>(dy + i * 8), g);
-    unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), xv);
+    unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dy + i * 8)), g);
+    unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(x + i * 8)), xv);
     if (from_x) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) yv[j] = xv[j] * sc[j] + sh[j];
