@@ -260,7 +260,20 @@ size_t isic_wgrad_c64_workspace_bytes(int N, int H, int W);
 int isic_wgrad_c64_launch(const uint16_t* x, const uint16_t* dy, float* dw, int N, int H, int W, void* workspace,
                           hipStream_t stream);
 
+// ... and of the 128 -> 128 3x3 layers (conv_wgrad_c128.hip)
+size_t isic_wgrad_c128_workspace_bytes(int N, int H, int W);
+int isic_wgrad_c128_launch(const uint16_t* x, const uint16_t* dy, float* dw, int N, int H, int W, void* workspace,
+                           hipStream_t stream);
+
 namespace {
+int g_wgrad_c128 = -1;    // env ISIC_WGRAD_C128=0 routes the 128 -> 128 layers through the generic kernel
+inline bool wgrad_c128_enabled() {
+  if (g_wgrad_c128 < 0) {
+    const char* e = getenv("ISIC_WGRAD_C128");
+    g_wgrad_c128 = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_wgrad_c128 != 0;
+}
 int g_wgrad_c64 = -1;     // env ISIC_WGRAD_C64=0 routes the 64 -> 64 layers through the generic kernel
 inline bool wgrad_c64_enabled() {
   if (g_wgrad_c64 < 0) {
@@ -281,6 +294,10 @@ size_t isic_conv2d_wgrad_workspace_bytes(int N, int Cin, int Hout, int Wout, int
     const size_t c64 = isic_wgrad_c64_workspace_bytes(N, Hout, Wout);
     if (c64 > need) need = c64;
   }
+  if (Cin == 128 && Cout == 128 && Kh == 3 && Kw == 3) {
+    const size_t c128 = isic_wgrad_c128_workspace_bytes(N, Hout, Wout);
+    if (c128 > need) need = c128;
+  }
   return need;
 }
 
@@ -300,6 +317,15 @@ int isic_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dw, int
     if (need != 0) {
       if (workspace_bytes < need) return ISIC_ERR_WORKSPACE;
       const int rc = isic_wgrad_c64_launch(x, dy, dw, N, Hin, Win, workspace, as_stream(stream));
+      return rc != ISIC_OK ? rc : isic_launch_status();
+    }
+  }
+  if (Cin == 128 && Cout == 128 && Kh == 3 && Kw == 3 && stride == 1 && pad == 1 && Hin == Hout && Win == Wout &&
+      wgrad_c128_enabled()) {
+    const size_t need = isic_wgrad_c128_workspace_bytes(N, Hin, Win);
+    if (need != 0) {
+      if (workspace_bytes < need) return ISIC_ERR_WORKSPACE;
+      const int rc = isic_wgrad_c128_launch(x, dy, dw, N, Hin, Win, workspace, as_stream(stream));
       return rc != ISIC_OK ? rc : isic_launch_status();
     }
   }

@@ -1,0 +1,278 @@
+// Weight gradient of the 128 -> 128 channel 3x3 / stride 1 / pad 1 layers (ResNet-18 layer2) with all nine taps per
+// block, on the plan of conv_wgrad_c64.hip (gfx950, bf16 MFMA, fp32 accumulate):
+//
+//   dW[co][kh][kw][ci] = sum over pixels p of  dY[p][co] * X[p + (kh-1, kw-1)][ci]
+//
+// The gradient of a 128 x 9 x 128 layer does not fit one block's registers, so the OUTPUT CHANNELS are split four ways:
+// block (slice q, pixel range) accumulates dW[32q .. 32q+32][9][128] -- 36,864 fp32, 72 accumulator VGPRs per MFMA
+// wave, as in the 64-channel kernel -- over a contiguous range of 4 x 32 pixel tiles.  Per tile four staging waves
+// bring the (4+2) x (32+2) pixel halo patch of X (all 128 input channels, 256-byte rows) and the block's 32-channel
+// slice of dY into LDS once, two stages deep; MFMA wave c owns input channels 16c .. 16c+16 for all taps and both
+// 16-channel halves of the slice.  X is staged by each of the four slice blocks (L2 hits), dY only by its own:
+// 121 staged bytes per MFMA against 250 for the one-tap-per-block kernel of conv_wgrad.hip.
+// Per-block partials go to the workspace with plain stores and are summed in a fixed order: no atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int T_H = 4, T_W = 32;                   // pixel tile
+constexpr int XPITCH = 40;                          // LDS pitch of the X patch in pixels (10 DMA groups of 4; 9 are loaded)
+constexpr int XROWS = T_H + 2;
+constexpr int XB = XROWS * XPITCH * 256;            // 61,440 B
+constexpr int YB = T_H * T_W * 64;                  // 8,192 B: [128 pixels][32 co]
+constexpr int STG = XB + YB;                        // 69,632 B
+constexpr int SCR = 2 * STG;                        // 1 KB landing zone of the padding DMAs
+constexpr int LDS_ALL = SCR + 1024;                 // 140,288 B
+constexpr int XGROUPS = XROWS * 9, YGROUPS = 8;     // 54 + 8 DMA groups per tile
+constexpr int NDMA128 = 16;                         // per staging wave (4 x 16 >= 62)
+constexpr int SLICE_ELEMS = 32 * 9 * 128;           // one block's partial gradient
+
+struct WC128Args {
+  const unsigned short* x;
+  const unsigned short* dy;
+  float* partial;       // [4 slices][blocks_per_slice][32][9][128]
+  int N, H, W, tiles_y, tiles_x, total_tiles, tiles_per_block, blocks_per_slice;
+};
+
+__device__ __attribute__((aligned(256))) unsigned char g_wc128_zeros[2048];
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {   // see conv_wgrad.hip
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__global__ __launch_bounds__(768) void wgrad_c128_kernel(WC128Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slice = blockIdx.x / a.blocks_per_slice, bs = blockIdx.x - slice * a.blocks_per_slice;
+  const int t_begin = bs * a.tiles_per_block;
+  const int ntl = min(a.total_tiles - t_begin, a.tiles_per_block);       // >= 1 by construction of the grid
+
+  if (wave12 >= 8) {
+    // =================================================================== staging waves (one per SIMD)
+    // DMA group d = p + 4j of a tile.  d < 54: X patch row d / 9, pixels 4 (d % 9) .. +4 (256 bytes each: lane ->
+    // pixel lane / 16, 16-byte slot lane % 16); 54 <= d < 62: dY pixels 16 (d - 54) .. +16 of the tile (64-byte slice
+    // rows: lane -> pixel lane / 4, slot lane % 4); else padding.
+    // X: the 32-byte granule G of patch pixel P = row * 40 + col holds input-channel block G ^ key(P),
+    //    key = (P & 3) | ((P >> 3) & 1) << 2  (P & 3 = col & 3, (P >> 3) & 1 = (row + (col >> 3)) & 1);
+    // dY: granule G of tile pixel P holds channel block G ^ ((P >> 3) & 1).  Both make the transposing reads of the
+    //    MFMA waves (8 pixel rows b..b+3, b+8..b+11 per half-wave) conflict-free for every tap shift.
+    const int p = wave12 - 8;
+    const int tiles_img = a.tiles_y * a.tiles_x;
+    struct Tile { int n, y0, x0; };
+    auto advance = [&](Tile& tl) {
+      tl.x0 += T_W;
+      if (tl.x0 >= a.W) {
+        tl.x0 = 0; tl.y0 += T_H;
+        if (tl.y0 >= a.H) { tl.y0 = 0; tl.n += 1; }
+      }
+    };
+    Tile ahead;
+    {
+      const int n = t_begin / tiles_img, rem = t_begin - n * tiles_img;
+      const int ty = rem / a.tiles_x;
+      ahead.n = n; ahead.y0 = ty * T_H; ahead.x0 = (rem - ty * a.tiles_x) * T_W;
+    }
+    const int xl_px = lane >> 4, xl_slot = lane & 15;              // X: pixel in group, 16-byte slot
+    const int yl_px = lane >> 2, yl_slot = lane & 3;               // dY: pixel in group, 16-byte slot of the 64-byte slice row
+    // byte offset of this lane's SOURCE chunk inside its pixel, for the two values of the wave-uniform key bit
+    const unsigned xsrc0 = (unsigned)(((((xl_slot >> 1) ^ xl_px) << 1) | (xl_slot & 1)) << 4);          // key = px & 3 (bit 2 clear)
+    const unsigned xsrc1 = (unsigned)(((((xl_slot >> 1) ^ (xl_px | 4)) << 1) | (xl_slot & 1)) << 4);    // bit 2 set
+    const unsigned ysrc = (unsigned)(((((yl_slot >> 1) ^ ((yl_px >> 3) & 1)) << 1) | (yl_slot & 1)) << 4);
+    const unsigned long long zeros = (unsigned long long)g_wc128_zeros;
+    auto issue_tile = [&](const Tile& tl, int stage, bool live) {
+      const long long org = ((long long)tl.n * a.H + tl.y0) * a.W + tl.x0;               // pixel index of the tile origin
+      const unsigned sbase = lds0 + (unsigned)stage * STG;
+#pragma unroll
+      for (int j = 0; j < NDMA128; ++j) {
+        const int d = p + 4 * j;                                                         // wave-uniform
+        unsigned long long src;
+        unsigned dst;
+        bool real = live;
+        if (d < XGROUPS) {
+          const int pr = d / 9, g = d - 9 * pr;
+          const int yy = tl.y0 - 1 + pr, xx = tl.x0 - 1 + 4 * g + xl_px;
+          const bool ok = real && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+          const unsigned long long pix = (unsigned long long)a.x +
+              (unsigned long long)((org + (long long)(pr - 1) * a.W - 1 + 4 * g + xl_px) * 256);
+          const int kv = (pr + (g >> 1)) & 1;                                            // ((row + (col >> 3)) & 1), col = 4g + ..
+          src = (ok ? pix : zeros) + (kv ? xsrc1 : xsrc0);
+          dst = sbase + (unsigned)((pr * XPITCH + 4 * g) * 256);
+        } else if (d < XGROUPS + YGROUPS) {
+          const int g2 = d - XGROUPS;
+          const int r = g2 >> 1, c = 16 * (g2 & 1) + yl_px;                              // tile row / column of this lane's pixel
+          const int yy = tl.y0 + r, xx = tl.x0 + c;
+          const bool ok = real && yy < a.H && xx < a.W;
+          const unsigned long long pix = (unsigned long long)a.dy +
+              (unsigned long long)((org + (long long)r * a.W + c) * 256 + slice * 64);
+          src = (ok ? pix : zeros) + ysrc;
+          dst = sbase + (unsigned)(XB + g2 * 1024);
+        } else {
+          real = false;
+          src = zeros + (unsigned)(lane * 16);
+          dst = 0;
+        }
+        glds16(reinterpret_cast<const void*>(src), real ? dst : lds0 + SCR);
+      }
+    };
+    issue_tile(ahead, 0, true);
+    advance(ahead);
+    for (int kk = 0; kk < ntl; ++kk) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile kk landed (this wave's groups)
+      __builtin_amdgcn_s_barrier();                       // ... every group; the MFMA waves are done with stage (kk+1)&1
+      issue_tile(ahead, (kk + 1) & 1, kk + 1 < ntl);
+      advance(ahead);
+    }
+    return;
+  }
+
+  // ======================================================================= MFMA waves: wave c = input channels 16c..16c+16
+  const int wave = wave12;
+  const int fg = lane >> 4, fi = lane & 15, fq = fi >> 2, fp = fi & 3;
+  // fragment addresses (bytes inside a stage).  X, tap column kw, half h, parity of the patch row:
+  // patch pixel column px = 8fg + fq + kw + 4h; key = (px & 3) | ((row + (px >> 3)) & 1) << 2
+  unsigned xaddr[3][2][2];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const int px = 8 * fg + fq + kw + 4 * h;
+        const int key = (px & 3) | (((par + (px >> 3)) & 1) << 2);
+        xaddr[kw][h][par] = (unsigned)(px * 256 + ((wave ^ key) << 5) + fp * 8);
+      }
+  // dY slice, 16-channel half c2: tile pixel s*32 + 8fg + fq (+4): key = (P >> 3) & 1 = fg & 1
+  unsigned yaddr[2];
+#pragma unroll
+  for (int c2 = 0; c2 < 2; ++c2) yaddr[c2] = (unsigned)(XB + (8 * fg + fq) * 64 + ((c2 ^ (fg & 1)) << 5) + fp * 8);
+
+  f32x4 acc[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int kk = 0; kk < ntl; ++kk) {
+    __builtin_amdgcn_s_barrier();              // the staging waves saw tile kk land
+    const unsigned st = lds0 + (unsigned)(kk & 1) * STG;
+    unsigned xb[3][2][2], yb[2];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { xb[kw][h][0] = st + xaddr[kw][h][0]; xb[kw][h][1] = st + xaddr[kw][h][1]; }
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) yb[c2] = st + yaddr[c2];
+    auto read_frag = [&](unsigned base_lo, unsigned base_hi, int off) -> bf16x8 {
+      s16x8_t t;
+      t.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(size_t)(base_lo + (unsigned)off));
+      t.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(size_t)(base_hi + (unsigned)off));
+      return __builtin_bit_cast(bf16x8, t);
+    };
+    bf16x8 yf[4][2];                            // dY fragments of the four 32-pixel rows (k-steps) x two co halves
+    bf16x8 xf[XROWS][3];                        // X fragments of patch row pr, tap column kw
+    auto read_row = [&](int pr) {
+      if (pr < T_H) {
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) yf[pr][c2] = read_frag(yb[c2], yb[c2] + 4 * 64, pr * 32 * 64);
+      }
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) xf[pr][kw] = read_frag(xb[kw][0][pr & 1], xb[kw][1][pr & 1], pr * XPITCH * 256);
+    };
+    read_row(0);
+#pragma unroll
+    for (int pr = 0; pr < XROWS; ++pr) {        // patch row pr serves k-step s = pr - kh of tap row kh
+      if (pr + 1 < XROWS) read_row(pr + 1);     // one row ahead of the MFMAs
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int s = pr - kh;
+        if (s < 0 || s >= T_H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2)
+            acc[kh * 3 + kw][c2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[pr][kw], yf[s][c2], acc[kh * 3 + kw][c2], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // this block's partial: lane (fg, fi) holds D[ci = 16c + 4fg + r][co = 32 slice + 16 c2 + fi]
+  float* part = a.partial + (size_t)blockIdx.x * SLICE_ELEMS;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+      *reinterpret_cast<f32x4*>(part + ((size_t)(c2 * 16 + fi) * 9 + t) * 128 + wave * 16 + fg * 4) = acc[t][c2];
+}
+
+// dw[32 slice + co][tap][ci] += sum over the slice's blocks (fixed order): thread (q, grp) sums blocks grp, grp+16, ...
+// of four consecutive elements, the 16 group sums are combined through LDS in group order
+__global__ __launch_bounds__(256) void wgrad_c128_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                 int blocks_per_slice) {
+  __shared__ f32x4 red[16][16];
+  const int q = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const size_t e4 = (size_t)blockIdx.x * 16 + q;                   // float4 index into the whole gradient
+  const int slice = (int)(e4 / (SLICE_ELEMS / 4));
+  const size_t l4 = e4 - (size_t)slice * (SLICE_ELEMS / 4);        // ... inside the slice
+  const float* base = partial + (size_t)slice * blocks_per_slice * SLICE_ELEMS;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f};
+  for (int b = grp; b < blocks_per_slice; b += 16) s0 += reinterpret_cast<const f32x4*>(base + (size_t)b * SLICE_ELEMS)[l4];
+  red[grp][q] = s0;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    f32x4 t = red[0][q];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) t += red[g][q];
+    f32x4* out = reinterpret_cast<f32x4*>(dw) + e4;
+    *out = *out + t;
+  }
+}
+
+int wc128_plan(int N, int H, int W, int* tiles_per_block) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+  }
+  const int per_slice = cus >= 4 ? cus / 4 : 1;
+  const int64_t total = (int64_t)N * ceil_div(H, T_H) * ceil_div(W, T_W);
+  const int tpb = (int)ceil_div64(total, per_slice);
+  if (tiles_per_block) *tiles_per_block = tpb;
+  return (int)ceil_div64(total, tpb);                              // blocks per slice
+}
+
+}  // namespace
+
+// bytes of workspace the 128 -> 128 kernel needs for N images of H x W (0: shape not handled)
+size_t isic_wgrad_c128_workspace_bytes(int N, int H, int W) {
+  if ((int64_t)N * ceil_div(H, T_H) * ceil_div(W, T_W) > 0x7FFFFFFFLL) return 0;
+  return (size_t)4 * wc128_plan(N, H, W, nullptr) * SLICE_ELEMS * sizeof(float);
+}
+
+// called by isic_conv2d_wgrad_bf16 for Cin = Cout = 128, 3x3, stride 1, pad 1
+int isic_wgrad_c128_launch(const uint16_t* x, const uint16_t* dy, float* dw, int N, int H, int W, void* workspace,
+                           hipStream_t stream) {
+  WC128Args a;
+  a.x = x; a.dy = dy; a.partial = reinterpret_cast<float*>(workspace);
+  a.N = N; a.H = H; a.W = W;
+  a.tiles_y = ceil_div(H, T_H); a.tiles_x = ceil_div(W, T_W);
+  a.total_tiles = N * a.tiles_y * a.tiles_x;
+  a.blocks_per_slice = wc128_plan(N, H, W, &a.tiles_per_block);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_c128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LDS_ALL) != hipSuccess)
+      return ISIC_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(wgrad_c128_kernel, dim3(4 * a.blocks_per_slice), dim3(768), LDS_ALL, stream, a);
+  hipLaunchKernelGGL(wgrad_c128_reduce_kernel, dim3(4 * SLICE_ELEMS / 64), dim3(256), 0, stream, a.partial, dw,
+                     a.blocks_per_slice);
+  return ISIC_OK;
+}

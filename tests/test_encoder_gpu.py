@@ -153,33 +153,36 @@ def test_conv_c64_kernels_match_generic(variant, shape):
         call("isic_debug_set_conv_variant", 5)
 
 
+@pytest.mark.parametrize("C", [64, 128])
 @pytest.mark.parametrize("shape", [(2, 13, 37), (40, 56, 56), (150, 56, 56), (37, 28, 40)])
-def test_conv_wgrad_c64_all_taps_kernel(shape):
-    """Weight gradient of the 64 -> 64 3x3 layers (persistent all-taps kernel, partials reduced in a fixed order)
-    against an fp64 reference built from nine shifted matrix products, at sizes that give a block 1, 3 and many
-    tiles; two runs must agree bit for bit (no atomics)."""
+def test_conv_wgrad_all_taps_kernels(shape, C):
+    """Weight gradient of the 64 -> 64 and 128 -> 128 3x3 layers (persistent all-taps kernels, partials reduced in a
+    fixed order) against an fp64 reference built from nine shifted matrix products, at sizes that give a block 1, 3
+    and many tiles; two runs must agree bit for bit (no atomics)."""
     from isic_hip.lib import call
     N, H, W = shape
+    if C == 128:
+        N = max(2, N // 2)
     g = torch.Generator().manual_seed(21)
-    x = torch.randn(N, H, W, 64, generator=g).to(DEV).to(BF)
-    dy = torch.randn(N, H, W, 64, generator=g).to(DEV).to(BF)
-    ws = torch.empty(call("isic_conv2d_wgrad_workspace_bytes", N, 64, H, W, 64, 3, 3), device=DEV, dtype=torch.uint8)
+    x = torch.randn(N, H, W, C, generator=g).to(DEV).to(BF)
+    dy = torch.randn(N, H, W, C, generator=g).to(DEV).to(BF)
+    ws = torch.empty(call("isic_conv2d_wgrad_workspace_bytes", N, C, H, W, C, 3, 3), device=DEV, dtype=torch.uint8)
 
     def run():
-        dw = torch.zeros(64, 3, 3, 64, device=DEV)                       # [co][kh][kw][ci]
-        call("isic_conv2d_wgrad_bf16", x, dy, dw, N, H, W, 64, H, W, 64, 3, 3, 1, 1, ws, ws.numel())
+        dw = torch.zeros(C, 3, 3, C, device=DEV)                         # [co][kh][kw][ci]
+        call("isic_conv2d_wgrad_bf16", x, dy, dw, N, H, W, C, H, W, C, 3, 3, 1, 1, ws, ws.numel())
         torch.cuda.synchronize()
         return dw
 
     got = run()
     xp = F.pad(x.double(), (0, 0, 1, 1, 1, 1))                           # pad W and H by 1
-    dyd = dy.double().reshape(-1, 64)
-    ref = torch.empty(64, 3, 3, 64, device=DEV, dtype=torch.float64)
+    dyd = dy.double().reshape(-1, C)
+    ref = torch.empty(C, 3, 3, C, device=DEV, dtype=torch.float64)
     for kh in range(3):
         for kw in range(3):
-            xs = xp[:, kh:kh + H, kw:kw + W, :].reshape(-1, 64)
+            xs = xp[:, kh:kh + H, kw:kw + W, :].reshape(-1, C)
             ref[:, kh, kw, :] = dyd.t() @ xs
-    assert_close(got.cpu(), ref.cpu(), rtol=2e-5, atol=1e-6, what=f"wgrad c64 {shape}")
+    assert_close(got.cpu(), ref.cpu(), rtol=2e-5, atol=1e-6, what=f"wgrad all-taps C={C} {shape}")
     assert torch.equal(got, run()), "the all-taps weight gradient must be reproducible run to run"
 
 
