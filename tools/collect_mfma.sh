@@ -17,6 +17,7 @@ def group(k):
     if "conv_igemm" in k: return "conv_igemm (>=128-channel and strided forward / data gradient)"
     if "conv3x3_c64" in k: return "conv3x3_c64p (64->64 forward / data gradient)"
     if "wgrad_c64_kernel" in k: return "wgrad_c64 (64->64 weight gradient)"
+    if "wgrad_c128_kernel" in k: return "wgrad_c128 (128->128 weight gradient)"
     if "conv_wgrad_kernel" in k: return "conv_wgrad (other weight gradients)"
     if "conv_stem" in k: return "conv_stem (forward + weight gradient)"
     return None

@@ -21,7 +21,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         k = r["Kernel_Name"]
         # isic_conv2d_igemm_bf16 dispatches the generic implicit GEMM or, for the 64 -> 64 3x3 layers, the halo kernels
         name = ("conv_igemm" if ("conv_igemm" in k or "conv3x3_c64" in k) else
-                "conv_wgrad" if ("conv_wgrad_kernel" in k or "wgrad_c64_kernel" in k) else None)
+                "conv_wgrad" if ("conv_wgrad_kernel" in k or "wgrad_c64_kernel" in k or "wgrad_c128_kernel" in k) else None)
         if name and r["Counter_Name"] == c:
             agg[name][0] += float(r["Counter_Value"]); agg[name][1].add(r["Dispatch_Id"])
     for k, (v, ids) in agg.items():
