@@ -469,7 +469,8 @@ int isic_conv2d_igemm_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out,
   ISIC_CHECK_ARG((stat_sum == nullptr) == (stat_sumsq == nullptr));
   ISIC_CHECK_ARG(!stat_sum || (stat_slots > 0 && down == 1));
   if (Cin % 64 != 0 || Cout % 64 != 0) return ISIC_ERR_UNSUPPORTED;
-  if ((int64_t)N * Hout * Wout > 0x7FFFFFFFLL || (int64_t)N * Hin * Win > 0x7FFFFFFFLL) return ISIC_ERR_UNSUPPORTED;
+  // element offsets inside the kernels are 32-bit: both whole tensors must stay below 2^31 elements
+  if ((int64_t)N * Hout * Wout * Cout > 0x7FFFFFFFLL || (int64_t)N * Hin * Win * Cin > 0x7FFFFFFFLL) return ISIC_ERR_UNSUPPORTED;
   if (Cin == 64 && Cout == 64 && Kh == 3 && Kw == 3 && up == 1 && down == 1 && pad == 1 && Hin == Hout && Win == Wout &&
       conv_c64_variant() != 0) {
     const int rc = isic_conv3x3_c64_launch(conv_c64_variant(), in, w, out, N, Hin, Win, addend, stat_sum, stat_sumsq, stat_slots,

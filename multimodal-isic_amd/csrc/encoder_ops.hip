@@ -567,6 +567,7 @@ int isic_bn_eval_affine(const float* gamma, const float* beta, const float* runn
 int isic_bn_apply_bf16(const uint16_t* x, const float* scale, const float* shift, const uint16_t* residual,
                        uint16_t* y, int64_t rows, int C, int relu, void* stream) {
   ISIC_CHECK_ARG(x && scale && shift && y && rows > 0 && C > 0 && C % 8 == 0);
+  if (!bn_c_ok(C)) return ISIC_ERR_UNSUPPORTED;   // per-thread channel constants: C/8 must divide the 256-thread block
   const int64_t nvec = rows * (C / 8);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), x, scale, shift,
                      residual, y, nullptr, nvec, C, relu);
@@ -576,6 +577,7 @@ int isic_bn_apply_bf16(const uint16_t* x, const float* scale, const float* shift
 int isic_bn_apply_mask_bf16(const uint16_t* x, const float* scale, const float* shift, const uint16_t* residual,
                             uint16_t* y, uint8_t* relu_mask, int64_t rows, int C, void* stream) {
   ISIC_CHECK_ARG(x && scale && shift && y && relu_mask && rows > 0 && C > 0 && C % 8 == 0);
+  if (!bn_c_ok(C)) return ISIC_ERR_UNSUPPORTED;   // per-thread channel constants: C/8 must divide the 256-thread block
   const int64_t nvec = rows * (C / 8);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), x, scale, shift,
                      residual, y, relu_mask, nvec, C, 1);
@@ -626,6 +628,7 @@ int isic_bn_bwd_apply_bf16(const uint16_t* dy, const uint16_t* x, const uint16_t
   ISIC_CHECK_ARG((scale == nullptr) == (shift == nullptr));
   ISIC_CHECK_ARG(!relu || y || scale);
   ISIC_CHECK_ARG((dgamma_f32 == nullptr) == (dbeta_f32 == nullptr));
+  if (!bn_c_ok(C)) return ISIC_ERR_UNSUPPORTED;   // per-thread channel constants: C/8 must divide the 256-thread block
   const int64_t nvec = rows * (C / 8);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), dy, x, y, nullptr,
                      mean, rstd, gamma, dgamma, dbeta, rows, C, relu, scale, shift, dx, d_residual, dgamma_f32, dbeta_f32);
@@ -638,6 +641,7 @@ int isic_bn_bwd_apply_mask_bf16(const uint16_t* dy, const uint16_t* x, const uin
                                 float* dbeta_f32, void* stream) {
   ISIC_CHECK_ARG(dy && x && relu_mask && mean && rstd && gamma && dgamma && dbeta && dx && rows > 0 && C > 0 && C % 8 == 0);
   ISIC_CHECK_ARG((dgamma_f32 == nullptr) == (dbeta_f32 == nullptr));
+  if (!bn_c_ok(C)) return ISIC_ERR_UNSUPPORTED;   // per-thread channel constants: C/8 must divide the 256-thread block
   const int64_t nvec = rows * (C / 8);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), dy, x, nullptr,
                      relu_mask, mean, rstd, gamma, dgamma, dbeta, rows, C, 1, nullptr, nullptr, dx, d_residual, dgamma_f32,

@@ -152,10 +152,18 @@ class GraphMIL(nn.Module):
     def set_dropout_state(self, seed, step=0):
         self.dropout_clock.seed, self.dropout_clock.step = int(seed), int(step)
 
+    @property
+    def graph_mode(self):
+        """CSR aggregation mode the layers need (``GraphBatch`` mode), ``None`` for the graph-free 'mlp'."""
+        return _GRAPH_MODE.get(self.gnn_type)
+
     def _graph(self, edge_index, edge_weight, n_nodes, graph):
         if self.gnn_type == 'mlp':
             return None
         if graph is not None:
+            if graph.mode != self.graph_mode:
+                raise ValueError(f"gnn_type '{self.gnn_type}' needs a '{self.graph_mode}'-mode GraphBatch, "
+                                 f"got '{graph.mode}'")
             return graph
         if edge_index is None:
             raise ValueError(f"gnn_type '{self.gnn_type}' needs edge_index")

@@ -65,6 +65,21 @@ def broadcast_parameters(flat_data, src=0, group=None):
         dist.broadcast(flat_data, src=src, group=group)
 
 
+def average_buffers(module, group=None):
+    """BatchNorm running statistics are updated from each rank's LOCAL batch (statistics are per rank, as in
+    torch DDP without SyncBatchNorm), so they drift apart; before evaluation / checkpointing every float buffer
+    is replaced by its mean over the ranks and integer buffers (``num_batches_tracked``) by rank 0's."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return
+    world = dist.get_world_size(group)
+    for b in module.buffers():
+        if b.dtype.is_floating_point:
+            dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
+            b.div_(world)
+        else:
+            dist.broadcast(b, src=0, group=group)
+
+
 def shard_range(n_items, rank, world):
     """Contiguous shard [lo, hi) of ``n_items`` bags for ``rank`` (sizes differ by at most 1)."""
     base, rem = divmod(n_items, world)

@@ -56,6 +56,27 @@ class GraphBatch:
              self.rowptr_t, self.col_t, self.val_t, self.perm_t, ws, nbytes)
 
 
+def _graph_from_parts(n_nodes, num_edges, mode, parts):
+    """A ``GraphBatch`` over CSR arrays that already exist on the device (no build launch): used by
+    ``train.GraphStore`` to assemble a step's batch out of per-graph pieces built once."""
+    if mode not in GraphBatch.MODES:
+        raise ValueError(f"unknown graph mode '{mode}'")
+    g = GraphBatch.__new__(GraphBatch)
+    g.n_nodes, g.num_edges, g.mode = int(n_nodes), int(num_edges), mode
+    for k in ("rowptr", "col", "val", "rowptr_t", "col_t", "val_t", "perm_t"):
+        t = parts[k]
+        want = torch.float32 if k.startswith("val") else torch.int32
+        if not t.is_cuda or t.dtype != want:
+            raise IsicHipError(f"GraphBatch.from_parts: {k} must be a device {want} tensor")
+        setattr(g, k, t.contiguous())
+    if g.rowptr.numel() != g.n_nodes + 1 or g.rowptr_t.numel() != g.n_nodes + 1:
+        raise ValueError("rowptr must have n_nodes + 1 entries")
+    return g
+
+
+GraphBatch.from_parts = staticmethod(_graph_from_parts)
+
+
 class SpmmFn(torch.autograd.Function):
     """out = alpha * A^ x (+ bias) (+ addend_scale * addend); backward through the transposed CSR."""
 

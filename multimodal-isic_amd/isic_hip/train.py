@@ -179,29 +179,101 @@ class GraphStore:
     """Graph records resident in HBM with their normalised CSR built once (graphs are static across
     epochs; the reference re-uploads x and edge_index every step, `05:340-343`)."""
 
-    def __init__(self, records, device, needs_graph=True):
-        self.device, self.records = device, records
+    def __init__(self, records, device, needs_graph=True, mode="gcn"):
+        """``mode``: aggregation of the CSR the model's layers need (``gnn_models._GRAPH_MODE``: 'gcn' =
+        self loops + symmetric normalisation, 'sum' = GINConv, 'mean' = SAGEConv)."""
+        if mode not in GraphBatch.MODES:
+            raise ValueError(f"unknown graph mode '{mode}'")
+        self.device, self.records, self.mode = device, records, mode
         self.x = [torch.as_tensor(np.asarray(r["x"], dtype=np.float32)).to(device) for r in records]
         self.y = np.asarray([int(r["y"]) for r in records])
         self.ei = [torch.as_tensor(np.asarray(r["edge_index"], dtype=np.int64)).to(device)
                    if needs_graph and r.get("edge_index") is not None else None for r in records]
         self.needs_graph = needs_graph
         self._single = {}
+        self._chunks = {}          # evaluation chunks (sequential index ranges) repeat every epoch: cached whole
+        self._stack = None
+        self._build_stack()
 
-    def batch(self, idx):
+    def _build_stack(self):
+        """Graphs are static across epochs, so their normalised CSR is built ONCE: one ``GraphBatch`` launch over
+        the whole record set.  When every graph has the same node and edge count (the reference's case: 196
+        nodes, k-NN / grid edges) the per-graph pieces are kept as [G, ...] stacks with LOCAL ids, and a step's
+        batch is six ``index_select``s plus offsets -- no per-step sort / scan / Python loop over graphs."""
+        if not self.needs_graph or not self.x or any(e is None for e in self.ei):
+            return
+        ns = {int(t.shape[0]) for t in self.x}
+        es = {int(e.shape[1]) for e in self.ei}
+        if len(ns) != 1 or len(es) != 1:
+            return
+        n, G = ns.pop(), len(self.x)
+        noff = torch.arange(G, device=self.device, dtype=torch.int64) * n
+        ei = (torch.stack(self.ei) + noff.view(G, 1, 1)).permute(1, 0, 2).reshape(2, -1)
+        full = GraphBatch(ei, G * n, mode=self.mode)
+        rp = full.rowptr.to(torch.int64)
+        rpt = full.rowptr_t.to(torch.int64)
+        used = int(rp[-1])                     # stored entries (the arrays are allocated for E + n)
+        nnz = used // G
+        if used != G * nnz or int(rpt[-1]) != used:
+            return
+        # graph g owns rows [g*n, (g+1)*n) and, because every graph has the same number of stored entries,
+        # slots [g*nnz, (g+1)*nnz) of both the CSR and its transpose
+        if not (bool((rp[::n] == torch.arange(G + 1, device=self.device) * nnz).all())
+                and bool((rpt[::n] == torch.arange(G + 1, device=self.device) * nnz).all())):
+            return
+        eoff = (torch.arange(G, device=self.device, dtype=torch.int64) * nnz).view(G, 1)
+        i32 = torch.int32
+        self._stack = {
+            "n": n, "nnz": nnz,
+            "rowptr": (rp[:-1].view(G, n) - eoff).to(i32), "rowptr_t": (rpt[:-1].view(G, n) - eoff).to(i32),
+            "col": (full.col[:used].view(G, nnz).to(torch.int64) - noff.view(G, 1)).to(i32),
+            "col_t": (full.col_t[:used].view(G, nnz).to(torch.int64) - noff.view(G, 1)).to(i32),
+            "val": full.val[:used].view(G, nnz).clone(), "val_t": full.val_t[:used].view(G, nnz).clone(),
+            "perm_t": (full.perm_t[:used].view(G, nnz).to(torch.int64) - eoff).to(i32),
+        }
+
+    def _stacked_graph(self, idx):
+        st = self._stack
+        n, nnz, B = st["n"], st["nnz"], len(idx)
+        sel = torch.as_tensor(idx, device=self.device, dtype=torch.int64)
+        i32 = torch.int32
+        noff = (torch.arange(B, device=self.device, dtype=i32) * n).view(B, 1)
+        eoff = (torch.arange(B, device=self.device, dtype=i32) * nnz).view(B, 1)
+        tail = torch.full((1,), B * nnz, device=self.device, dtype=i32)
+        parts = {
+            "rowptr": torch.cat([(st["rowptr"][sel] + eoff).reshape(-1), tail]),
+            "rowptr_t": torch.cat([(st["rowptr_t"][sel] + eoff).reshape(-1), tail]),
+            "col": (st["col"][sel] + noff).reshape(-1), "col_t": (st["col_t"][sel] + noff).reshape(-1),
+            "val": st["val"][sel].reshape(-1), "val_t": st["val_t"][sel].reshape(-1),
+            "perm_t": (st["perm_t"][sel] + eoff).reshape(-1),
+        }
+        return GraphBatch.from_parts(B * n, B * (nnz - (n if self.mode == "gcn" else 0)), self.mode, parts)
+
+    def batch(self, idx, cache=False):
+        """(x[sum n, D], offsets, GraphBatch) of the graphs ``idx``; ``cache=True`` keeps the result (evaluation
+        chunks, which repeat every epoch)."""
+        key = tuple(int(i) for i in idx)
+        if cache and key in self._chunks:
+            return self._chunks[key]
         xs = [self.x[i] for i in idx]
         lens = [int(t.shape[0]) for t in xs]
         offs = BagOffsets.from_lengths(lens, self.device)
         if len(idx) == 1:
             i = idx[0]
             if self.needs_graph and i not in self._single:
-                self._single[i] = GraphBatch(self.ei[i], lens[0])
+                self._single[i] = GraphBatch(self.ei[i], lens[0], mode=self.mode)
             return xs[0], offs, self._single.get(i)
         graph = None
         if self.needs_graph:
-            ei = torch.cat([self.ei[i] + int(o) for i, o in zip(idx, offs.host[:-1])], dim=1)
-            graph = GraphBatch(ei, offs.total)
-        return torch.cat(xs), offs, graph
+            if self._stack is not None:
+                graph = self._stacked_graph(key)
+            else:
+                ei = torch.cat([self.ei[i] + int(o) for i, o in zip(idx, offs.host[:-1])], dim=1)
+                graph = GraphBatch(ei, offs.total, mode=self.mode)
+        out = (torch.cat(xs), offs, graph)
+        if cache:
+            self._chunks[key] = out
+        return out
 
 
 def gnn_metrics(labels, scores, num_classes):
@@ -226,7 +298,7 @@ def evaluate_gnn(model, store, num_classes, chunk=32):
     scores, losses = [], []
     for lo in range(0, n, chunk):
         idx = list(range(lo, min(n, lo + chunk)))
-        x, offs, g = store.batch(idx)
+        x, offs, g = store.batch(idx, cache=True)
         probs, _ = model(x, offsets=offs, graph=g)
         y = torch.as_tensor(store.y[idx], device=x.device)
         losses.append(ops.CrossEntropyFn.apply(probs, y, 1)[1].cpu())      # CE(log(p + 1e-9)), 05:282
@@ -243,7 +315,8 @@ def train_gnn_fold(model, train_records, val_records, test_records, *, lr=1e-4, 
     rank, world = dist_info()
     device = device or next(model.parameters()).device
     needs = model.gnn_type != "mlp"
-    tr, va, te = (GraphStore(r, device, needs) for r in (train_records, val_records, test_records))
+    mode = model.graph_mode or "gcn"
+    tr, va, te = (GraphStore(r, device, needs, mode=mode) for r in (train_records, val_records, test_records))
     opt = optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
     ddp.broadcast_parameters(opt.flat.data)
     sync = ddp.GradSync(opt.flat.grad, world_size=world)

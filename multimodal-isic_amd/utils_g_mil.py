@@ -23,16 +23,26 @@ from isic_hip.bags import BagOffsets, as_offsets
 
 class _DropoutClock:
     """Counter-based dropout state shared by a module's dropout sites: stream id =
-    step * 1024 + site, so every (step, site, element) draws an independent word."""
+    step * 1024 + site (+ rank << 44 under data parallelism), so every (rank, step, site, element)
+    draws an independent word.  Element indices are local to a rank's shard of the step's bags, so
+    without the rank term every shard would see the same mask; with it the shards' masks are
+    independent, as the rows of one big batch are."""
 
-    def __init__(self, seed=None):
+    def __init__(self, seed=None, rank=None):
         self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
         self.step = 0
+        self.rank = rank       # None: torch.distributed rank at use time (0 when not initialised)
+
+    def _rank(self):
+        if self.rank is not None:
+            return int(self.rank)
+        import torch.distributed as dist
+        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
     def spec(self, p, site, training):
         if not training or p <= 0.0:
             return None
-        return ops.DropoutSpec(p, self.seed, self.step * 1024 + site)
+        return ops.DropoutSpec(p, self.seed, (self._rank() << 44) + self.step * 1024 + site)
 
 
 class _MILBase(nn.Module):

@@ -87,6 +87,65 @@ def test_gnn_training_auroc_parity():
     assert set(vm) == {"loss", "accuracy", "bacc", "auc", "macro_f1"} and best == 1
 
 
+@pytest.mark.parametrize("gnn_type", ["graphsage", "gin", "gcn"])
+def test_graphstore_mode_and_fold_loop_parity(gnn_type):
+    """`train_gnn_fold` must hand every model the CSR its layers need (SAGEConv = neighbour mean, GINConv =
+    neighbour sum, no self loops): per-graph steps of the packaged fold loop == the CPU oracle loop
+    (`05_train_gnns.py:336-358`), parameters after one epoch within 2e-4 and validation AUROC within 0.002."""
+    import build_graphs as bg
+    from dataset import synthetic_latent_bags
+    from gnn_models import GraphMIL, _GRAPH_MODE
+    from isic_hip import train as T
+    bags, labels = synthetic_latent_bags(36, 25, 16, classes=7, shift=0.8, seed=9)
+    recs = [{"x": b, "edge_index": bg._knn_edge_index(torch.from_numpy(b), 3).numpy(), "y": int(y)} for b, y in zip(bags, labels)]
+    tr, va = recs[:24], recs[24:]
+    cfg = dict(gnn_type=gnn_type, gnn_hidden=16, gnn_layers=2, gnn_dropout=0.0, att_dim=8, classifier_dim=12, pool_dropout=0.0)
+    torch.manual_seed(3)
+    m = GraphMIL(16, gnn_type, 16, 2, 0.0, att_dim=8, att_heads=4, pool_dropout=0.0, classifier_dim=12,
+                 classifier_light=True, num_classes=7)
+    p0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV)
+    store = T.GraphStore(tr, torch.device(DEV), True, mode=_GRAPH_MODE[gnn_type])
+    assert store.batch([0])[2].mode == _GRAPH_MODE[gnn_type] and store.batch([0, 1])[2].mode == _GRAPH_MODE[gnn_type]
+    if gnn_type != "gcn":
+        with pytest.raises(ValueError):      # a GCN-normalised graph must not reach a SAGE / GIN model silently
+            g = T.GraphStore(tr, torch.device(DEV), True, mode="gcn").batch([0])
+            m(g[0], offsets=g[1], graph=g[2])
+    rs = np.random.RandomState(21)
+    order = np.random.RandomState(21).permutation(len(tr))
+    vm, _, best = T.train_gnn_fold(m, tr, va, va[:4], lr=2e-3, weight_decay=1e-4, epochs=1, graphs_per_step=1,
+                                   num_classes=7, device=torch.device(DEV), rng=rs)
+    p1, ohist = otrain.train_gnn(p0, cfg, tr, va, lr=2e-3, weight_decay=1e-4, epochs=1, orders=[order])
+    for k, v in m.state_dict().items():
+        assert float((v.cpu() - p1[k]).abs().max()) < 2e-4, k
+    assert abs(vm["auc"] - ohist[0]["val_auc"]) <= 0.002
+
+
+@pytest.mark.parametrize("mode", ["gcn", "sum", "mean"])
+def test_graphstore_stacked_csr_equals_built_csr(mode):
+    """A step's batch assembled from the per-graph CSR pieces built once == the CSR built from the batch's
+    concatenated edge list (bit-exact arrays, both orientations)."""
+    import build_graphs as bg
+    from dataset import synthetic_latent_bags
+    from isic_hip import train as T
+    from isic_hip.graph import GraphBatch
+    bags, labels = synthetic_latent_bags(12, 30, 8, classes=3, shift=0.5, seed=2)
+    recs = [{"x": b, "edge_index": bg._knn_edge_index(torch.from_numpy(b), 5).numpy(), "y": int(y)} for b, y in zip(bags, labels)]
+    store = T.GraphStore(recs, torch.device(DEV), True, mode=mode)
+    assert store._stack is not None
+    idx = [7, 2, 11, 2]
+    x, offs, g = store.batch(idx)
+    ei = torch.cat([store.ei[i] + 30 * j for j, i in enumerate(idx)], dim=1)
+    ref = GraphBatch(ei, 120, mode=mode)
+    used = int(ref.rowptr[-1])
+    assert g.n_nodes == 120 and int(g.rowptr[-1]) == used and g.num_edges == ref.num_edges
+    for k in ("rowptr", "rowptr_t"):
+        assert torch.equal(getattr(g, k), getattr(ref, k)), k
+    for k in ("col", "val", "col_t", "val_t", "perm_t"):
+        assert torch.equal(getattr(g, k)[:used], getattr(ref, k)[:used]), k
+    assert torch.equal(x, torch.cat([store.x[i] for i in idx]))
+
+
 def test_pipeline_01_02_03_05_synthetic(tmp_path):
     """teacher (01) -> patch stats (02) -> graphs (03) -> GNN (05) on a small synthetic set, through the
     drop-in scripts; checks the pickle / CSV schemas the reference defines."""
