@@ -1,22 +1,26 @@
-"""Headline benchmark: bags/sec of the attention-MIL train step (fwd + bwd + AdamW, grad
-all-reduce when N > 1) on ISIC-shaped synthetic bags: 64 patches of 3x224x224 per bag +
-a 128-d radiomic vector, ResNet-18 patch encoder, bf16 MFMA convolutions.
+"""Headline benchmark of the attention-MIL + patch-graph GNN training path on the MI355X.
 
-    python bench.py --gpus 1 --steps 8 --warmup 2
+    python bench.py --gpus 1 --steps 8 --warmup 2                     # configs[1]: attention-MIL, ResNet-18 encoder
+    python bench.py --config gnn --gpus 1 --steps 20 --warmup 5       # configs[3]: patch-graph GNN (05_train_gnns.py path)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the repo instructions): whole-job bags/s with
-inputs resident in HBM, plus
-  "roofline":     dominant kernel (implicit-GEMM convolution) algorithmic FLOP/s, measured
-                  with HIP events around every launch of the timed region, vs the dense
-                  bf16 MFMA peak (2.5 PFLOP/s);
-  "cpu_baseline": the CPU oracle's per-bag training loop (reference loop shape,
-                  01_train_mil_teacher.py:235-246) timed on the host cores, rank 0, N = 1.
+Prints ONE JSON line on rank 0 (contract in the repo instructions): whole-job units/s (bags or graphs) with
+inputs resident in HBM when the timed region starts, plus
+  "roofline":     the dominant kernel's algorithmic FLOP/s (mil: implicit-GEMM convolution forward + data gradient
+                  vs the dense bf16 MFMA peak) or GB/s (gnn: the segmented-sum SpMM vs the HBM peak), from HIP events
+                  around every launch of that C-ABI entry INSIDE the timed region, on the stream it is launched on;
+  "kernel_time":  per-class kernel time per step from an instrumented pass AFTER the timed region (every C-ABI
+                  launch bracketed by HIP events), so that host gaps and clock throttling can be told apart:
+                  gpu_busy_ms_per_step vs ms_per_step vs host_enqueue_ms_per_step;
+  "cpu_baseline": the CPU oracle's per-bag / per-graph training loop (the reference's loop shape,
+                  01_train_mil_teacher.py:235-246 / 05_train_gnns.py:336-346) timed on the host cores, rank 0, N = 1,
+                  at all threads and at one thread.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -30,27 +34,54 @@ import torch
 import torch.distributed as dist
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
-WORKLOAD = ("ISIC-shaped attention-MIL: 256 bags x 64x224x224 patches + 128-d radiomics, "
-            "ResNet-18 encoder, bf16 (BASELINE.json configs[1])")
+HBM_PEAK_GBS = 8000.0            # HBM3E spec, same guide (6.3 TB/s measured streaming)
+WORKLOAD_MIL = ("ISIC-shaped attention-MIL: 256 bags x 64x224x224 patches + 128-d radiomics, "
+                "ResNet-18 encoder, bf16 (BASELINE.json configs[1])")
+WORKLOAD_GNN = ("Patch-graph GNN (05_train_gnns.py path): k-NN (k=8) graphs of 196 nodes on 768-d patch embeddings, "
+                "3-layer GCN F=128, 4-head attention pool (BASELINE.json configs[3])")
 
 
-def conv_flops(spec_args):
-    """Algorithmic FLOPs of one isic_conv2d_igemm_bf16 launch (2*M*Cout*K of the convolution it
-    implements; for a data-gradient launch that is the forward convolution's count)."""
-    (_in, _w, _out, N, Hin, Win, Cin, Hout, Wout, Cout, Kh, Kw, up, down, pad) = spec_args[:15]
-    if down == 1:      # forward: out pixels x Cout x (Kh*Kw*Cin)
-        return 2.0 * N * Hout * Wout * Cout * Kh * Kw * Cin
-    # dgrad with stride `down`: only 1/down^2 of the taps hit a real dY pixel
-    return 2.0 * N * Hout * Wout * Cout * Kh * Kw * Cin / (down * down)
+# ----------------------------------------------------------------------------------------------- instrumentation
+def conv_flops(a):
+    """Algorithmic FLOPs of one isic_conv2d_igemm_bf16 launch (2*M*Cout*K of the convolution it implements; for a
+    data-gradient launch that is the forward convolution's count).  ``a`` = the call's arguments after the three
+    tensors: (N, Hin, Win, Cin, Hout, Wout, Cout, Kh, Kw, up, down, pad, ...)."""
+    N, Hin, Win, Cin, Hout, Wout, Cout, Kh, Kw, up, down, pad = a[:12]
+    f = 2.0 * N * Hout * Wout * Cout * Kh * Kw * Cin
+    return f if down == 1 else f / (down * down)      # stride-`down` dgrad: 1/down^2 of the taps hit a real dY pixel
+
+
+KERNEL_CLASSES = (
+    ("conv_fwd_dgrad", ("isic_conv2d_igemm_bf16",)),
+    ("conv_wgrad", ("isic_conv2d_wgrad",)),
+    ("stem_conv", ("isic_conv_stem",)),
+    ("bn_pool", ("isic_bn_", "isic_maxpool", "isic_avgpool")),
+    ("graph", ("isic_spmm", "isic_gat", "isic_gcn_csr", "isic_knn", "isic_l2normalize", "isic_edge", "isic_fa",
+               "isic_transformer", "isic_hetero")),
+    ("attn_pool", ("isic_attn_pool",)),
+    ("gemm_f32", ("isic_gemm", "isic_colsum")),
+)
+
+
+def kernel_class(name):
+    for cls, prefixes in KERNEL_CLASSES:
+        if any(name.startswith(p) for p in prefixes):
+            return cls
+    return "other"            # layer norm, cross entropy, dropout, AdamW, weight prep, layout packs
 
 
 class KernelTimer:
-    """HIP-event timing of selected C-ABI launches on the stream they are launched on."""
+    """HIP-event timing of C-ABI launches on the stream they are launched on.  ``names``: the entries to time
+    (None = every entry).  Events come from a pool, so a timed launch costs two ``record`` calls and no allocation."""
 
-    def __init__(self, names):
-        self.names = set(names)
+    def __init__(self):
+        self.names = None
         self.records = []
         self.active = False
+        self._pool = []
+
+    def _event(self):
+        return self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
 
     def install(self):
         from isic_hip import lib
@@ -58,56 +89,83 @@ class KernelTimer:
         timer = self
 
         def timed_call(name, *args, stream=None):
-            if timer.active and name in timer.names:
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
+            if timer.active and (timer.names is None or name in timer.names):
+                e0, e1 = timer._event(), timer._event()
                 e0.record()
                 rc = orig(name, *args, stream=stream)
                 e1.record()
-                timer.records.append((name, args[3:], e0, e1))
+                timer.records.append((name, args, e0, e1))
                 return rc
             return orig(name, *args, stream=stream)
 
         lib.call = timed_call
-        import isic_hip.encoder as enc
-        import isic_hip.ops as ops
-        enc.call = timed_call
-        ops.call = timed_call
+        import isic_hip
+        for modname in ("encoder", "ops", "graph", "optim", "hetero"):
+            mod = getattr(isic_hip, modname, None)
+            if mod is None:
+                try:
+                    mod = __import__(f"isic_hip.{modname}", fromlist=[modname])
+                except ImportError:
+                    continue
+            if hasattr(mod, "call"):
+                mod.call = timed_call
 
-    def summary(self):
-        total_ms, total_flops, n = 0.0, 0.0, 0
-        for name, a, e0, e1 in self.records:
-            total_ms += e0.elapsed_time(e1)
-            total_flops += conv_flops((None, None, None) + tuple(a))
-            n += 1
-        return n, total_ms, total_flops
+    def start(self, names):
+        self.names = None if names is None else set(names)
+        self.records = []
+        self.active = True
+
+    def stop(self):
+        """-> list of (name, args, ms); call after a device synchronisation."""
+        self.active = False
+        out = []
+        for name, args, e0, e1 in self.records:
+            out.append((name, args, e0.elapsed_time(e1)))
+            self._pool += [e0, e1]
+        self.records = []
+        return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--bags-per-step", type=int, default=16, help="bags per optimizer step PER GPU")
-    ap.add_argument("--patches", type=int, default=64)
-    ap.add_argument("--image-size", type=int, default=224)
-    ap.add_argument("--radiomics-dim", type=int, default=128)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
-    args = ap.parse_args()
+def kernel_source_hash():
+    """Identity of the kernels a profile was taken with: sha256 over csrc/*.hip and csrc/*.h."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "multimodal-isic_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+def pmc_traffic(key, **match):
+    """HBM bytes per launch of the roofline kernel from the rocprofv3 PMC passes of THIS command (counters need runs
+    of their own: tools/collect_traffic.sh), committed under profiles/.  The profile is stamped with the kernel
+    source hash and the workload; anything that does not match the code being run is refused (-> None)."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    if d.get("kernel_source_hash") != kernel_source_hash():
+        return None
+    if any(d.get(k) != v for k, v in match.items()):
+        return None
+    return d.get(key)
+
+
+def split_by_class(records, steps):
+    per = {}
+    for name, _a, ms in records:
+        c = kernel_class(name)
+        per[c] = per.get(c, 0.0) + ms
+    out = {k: v / steps for k, v in sorted(per.items(), key=lambda kv: -kv[1])}
+    out["gpu_busy_ms_per_step"] = sum(per.values()) / steps
+    out["launches_per_step"] = len(records) / steps
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- configs[1]: MIL
+def run_mil(args, world, rank, dev):
     from isic_hip import ddp, optim
     from model import MultiModalMILNet
 
@@ -120,13 +178,7 @@ def main():
     flat = opt.flat
     ddp.broadcast_parameters(flat.data)
     sync = ddp.GradSync(flat.grad, world_size=world)
-    offset_of = {id(p): o for p, o in zip(flat.params, flat.offsets)}
-    enc_names = {n: offset_of[id(p)] for n, p in model.encoder.named_parameters()}
-    head_lo = max(enc_names.values()) + 1   # everything after the encoder's last tensor start
-
-    def hook(names):
-        sync.mark_ready(min(enc_names[n] for n in names))
-    model.encoder.grad_ready_hook = hook
+    ddp.attach(model.encoder, flat, sync)
 
     # synthetic ISIC-shaped data, resident in HBM (bf16 images as the dataset loader would hand them over)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -136,7 +188,7 @@ def main():
                + 0.25 * labels[s].view(B, 1, 1, 1, 1).float()).to(torch.bfloat16) for s in range(n_sets)]
     radiom = [torch.randn(B, R, device=dev, generator=g) + 0.25 * labels[s].view(B, 1).float() for s in range(n_sets)]
 
-    timer = KernelTimer(["isic_conv2d_igemm_bf16"])
+    timer = KernelTimer()
     timer.install()
 
     def step(i):
@@ -153,15 +205,206 @@ def main():
     # two untimed settle steps (allocator growth, kernel attribute setup) precede the W warm-up steps
     for i in range(2 + args.warmup):
         step(i)
+    elapsed, host_s, loss = timed_region(step, args, world, dev, timer, ["isic_conv2d_igemm_bf16"], 2 + args.warmup)
+    conv = timer.stop()
+    final_loss = float(loss.detach())
+    split = instrumented_pass(step, timer, dev, world, start=2 + args.warmup + args.steps)
+    ddp.average_buffers(model)           # BatchNorm running statistics are per rank during training
+
+    if rank != 0:
+        return None
+    conv_ms = sum(ms for _n, _a, ms in conv)
+    conv_fl = sum(conv_flops(a[3:]) for _n, a, _ms in conv)
+    n_launch = len(conv)
+    achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    line = base_line("bags/sec (train step) @ 64x224x224 patches/bag", "bags/s", world * B * args.steps / elapsed,
+                     world, args, elapsed, "bf16")
+    line["config"] = {"workload": WORKLOAD_MIL, "bags_per_step_per_gpu": B, "global_bags_per_step": B * world,
+                      "patches_per_bag": K, "patch": f"3x{S}x{S}", "radiomics_dim": R, "parallelism": f"dp{world}",
+                      "host_enqueue_ms_per_step": host_s * 1e3 / args.steps, "final_loss": final_loss}
+    line["roofline"] = {
+        "bound": "mfma", "kernel": "C-ABI entry isic_conv2d_igemm_bf16 (forward + data gradient of every non-stem "
+                                   "convolution: conv_igemm_kernel / conv_halo kernels)",
+        "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
+        "traffic": pmc_traffic("conv_igemm_hbm_bytes_per_launch", bags_per_step=B, patches=K, image_size=S),
+        "launches": n_launch, "avg_launch_ms": conv_ms / max(n_launch, 1),
+        "algorithmic_gflop_per_launch": conv_fl / max(n_launch, 1) / 1e9,
+        "share_of_step_time": conv_ms * 1e-3 / elapsed, "measured": "HIP events inside the timed region",
+    }
+    line["kernel_time"] = split
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_mil(model, K, S, R, C, args.cpu_budget_s)
+    return line
+
+
+def cpu_baseline_mil(model, K, S, R, C, budget_s):
+    """oracle/ per-bag loop on the host cores (kind "port": the build's CPU restatement of the reference loop; the
+    reference itself cannot travel to the GPU box).  One full bag is ~692 GFLOP of fp32 convolution, so the sample is
+    per-bag optimizer steps on REDUCED bags (k patches instead of K) and the rate is scaled by k / K -- the
+    convolutions are >99.9 % of the work and linear in the patch count."""
+    from oracle import model as omodel
+    p = {k: v.detach().float().cpu().contiguous() for k, v in model.state_dict().items()
+         if v.dtype.is_floating_point and "running_" not in k}
+    threads = torch.get_num_threads()
+
+    def run(k_patches, n_steps, nthreads, budget):
+        torch.set_num_threads(nthreads)
+        g = torch.Generator().manual_seed(7)
+        bags = [(torch.randn(k_patches, 3, S, S, generator=g) + 0.25 * (i % C), torch.randn(1, R, generator=g) + 0.25 * (i % C),
+                 i % C) for i in range(n_steps + 1)]
+        sps, done = omodel.time_per_bag_train_loop(p, lambda i: bags[i], n_bags=n_steps, warmup=1, budget_s=budget)
+        torch.set_num_threads(threads)
+        return sps * k_patches / K, done
+
+    k_all, k_one = 8, 2
+    v_all, d_all = run(k_all, 12, threads, budget_s)
+    v_one, d_one = run(k_one, 4, 1, budget_s)
+    return {"value": v_all, "unit": "bags/s", "cores": threads, "kind": "port",
+            "sample": f"{d_all} per-bag train steps on bags reduced to {k_all} of {K} patches (3x{S}x{S}, fp32, torch CPU, "
+                      f"{threads} threads) after 1 warm-up step; rate scaled by {k_all}/{K}",
+            "one_thread": {"value": v_one, "cores": 1,
+                           "sample": f"{d_one} steps on bags of {k_one} patches, scaled by {k_one}/{K}"},
+            "host_cpus": os.cpu_count()}
+
+
+# ----------------------------------------------------------------------------------------------- configs[3]: GNN
+def run_gnn(args, world, rank, dev):
+    import numpy as np
+    from gnn_models import GraphMIL
+    from isic_hip import ddp, ops, optim, train as T
+    from isic_hip.bags import BagOffsets
+    from isic_hip.graph import knn_indices
+
+    N, D, F, L, k, C = args.nodes, args.feat, args.hidden, args.gnn_layers, args.knn_k, 7
+    Gs = args.graphs_per_step
+    n_graphs = max(2 * Gs, 512)
+    torch.manual_seed(42)
+    model = GraphMIL(input_dim=D, gnn_type="gcn", gnn_hidden=F, gnn_layers=L, gnn_dropout=0.5, gnn_heads=4, att_dim=128,
+                     att_heads=4, pool_dropout=0.2, classifier_dim=128, classifier_light=True, num_classes=C).to(dev)
+    model.train()
+    model.set_dropout_state(seed=42, step=0)
+    opt = optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)
+    ddp.broadcast_parameters(opt.flat.data)
+    sync = ddp.GradSync(opt.flat.grad, world_size=world)
+
+    # synthetic graph records resident in HBM: node features with a class-dependent shift, k-NN edges built on device
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    y = (torch.arange(n_graphs, device=dev) + rank) % C
+    x = torch.randn(n_graphs, N, D, device=dev, generator=gen) + 0.25 * y.view(-1, 1, 1).float()
+    offs = BagOffsets.from_lengths([N] * n_graphs, dev)
+    nn_idx = knn_indices(x.view(-1, D), offs, k).view(n_graphs, N, k)
+    src = torch.arange(N, device=dev).view(1, N, 1).expand(n_graphs, N, k)
+    ei = torch.stack([src.reshape(n_graphs, -1), nn_idx.reshape(n_graphs, -1)], dim=1)      # [G, 2, N*k], local ids
+    records = [{"x": x[i], "edge_index": ei[i], "y": int(y[i])} for i in range(n_graphs)]
+    store = T.GraphStore(records, dev, True, mode=model.graph_mode)
+    rs = np.random.RandomState(7 + rank)
+
+    timer = KernelTimer()
+    timer.install()
+
+    def step(i):
+        idx = rs.randint(0, n_graphs, size=Gs).tolist()
+        xb, ob, gb = store.batch(idx)
+        opt.zero_grad()
+        sync.reset()
+        probs, _ = model(xb, offsets=ob, graph=gb)
+        loss = ops.cross_entropy_from_probs(probs, torch.as_tensor(store.y[idx], device=dev))
+        loss.backward()
+        sync.finish()
+        opt.step(grad_scale=1.0 / world)
+        return loss
+
+    for i in range(2 + args.warmup):
+        step(i)
+    elapsed, host_s, loss = timed_region(step, args, world, dev, timer, ["isic_spmm_csr_f32"], 2 + args.warmup)
+    spmm = timer.stop()
+    final_loss = float(loss.detach())
+    split = instrumented_pass(step, timer, dev, world, start=0)
+    if rank != 0:
+        return None
+    # compulsory bytes of one segmented-sum launch over the step's Gs graphs (SURVEY.md 8d): read h + write out +
+    # col + val + rowptr; E counts the self loops GCNConv adds
+    E = N * k + N
+    per_graph = 2 * N * F * 4 + 2 * E * 4 + (N + 1) * 4
+    ms = sum(m for _n, _a, m in spmm)
+    n_launch = len(spmm)
+    achieved = Gs * per_graph * n_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    line = base_line("graphs/sec (GNN train step) @ 196-node k-NN patch graphs", "graphs/s",
+                     world * Gs * args.steps / elapsed, world, args, elapsed, "f32")
+    line["config"] = {"workload": WORKLOAD_GNN, "graphs_per_step_per_gpu": Gs, "nodes": N, "feat": D, "hidden": F,
+                      "layers": L, "knn_k": k, "parallelism": f"dp{world}",
+                      "host_enqueue_ms_per_step": host_s * 1e3 / args.steps, "final_loss": final_loss}
+    line["roofline"] = {
+        "bound": "hbm", "kernel": "C-ABI entry isic_spmm_csr_f32 (GCNConv aggregation: neighbour gather + segmented sum, "
+                                  "forward and transposed backward)",
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": pmc_traffic("spmm_hbm_bytes_per_launch", graphs_per_step=Gs, nodes=N, hidden=F),
+        "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1),
+        "algorithmic_bytes_per_launch": Gs * per_graph, "compulsory_bytes_per_layer_per_graph": per_graph,
+        "share_of_step_time": ms * 1e-3 / elapsed, "measured": "HIP events inside the timed region",
+    }
+    line["kernel_time"] = split
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_gnn(model, records, args.cpu_budget_s)
+    return line
+
+
+def cpu_baseline_gnn(model, records, budget_s):
+    """oracle/ per-graph 05 loop (`05_train_gnns.py:336-346`: one graph per optimizer step, fp32, torch CPU, AdamW)."""
+    from oracle import gnn as ognn
+    cfg = dict(gnn_type="gcn", gnn_hidden=model.gnn_layers[0].lin.weight.shape[0], gnn_layers=len(model.gnn_layers),
+               gnn_dropout=0.0, att_dim=128, classifier_dim=128, pool_dropout=0.0)
+    p0 = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    recs = [{"x": r["x"].cpu(), "edge_index": r["edge_index"].cpu(), "y": r["y"]} for r in records[:64]]
+    threads = torch.get_num_threads()
+
+    def run(nthreads, warm, n_steps, budget):
+        torch.set_num_threads(nthreads)
+        q = {k: torch.nn.Parameter(v.clone()) for k, v in p0.items()}
+        opt = torch.optim.AdamW(list(q.values()), lr=1e-4, weight_decay=1e-4)
+
+        def one(i):
+            r = recs[i % len(recs)]
+            opt.zero_grad()
+            out = ognn.graphmil_forward(q, cfg, r["x"], r["edge_index"])
+            ognn.graph_loss(out["probs"], r["y"]).backward()
+            opt.step()
+        for i in range(warm):
+            one(i)
+        t0 = time.perf_counter()
+        done = 0
+        for i in range(n_steps):
+            one(warm + i)
+            done += 1
+            if time.perf_counter() - t0 > budget:
+                break
+        dt = time.perf_counter() - t0
+        torch.set_num_threads(threads)
+        return done / dt, done
+
+    v_all, d_all = run(threads, 30, 400, budget_s / 2)
+    v_one, d_one = run(1, 30, 400, budget_s / 2)
+    return {"value": v_all, "unit": "graphs/s", "cores": threads, "kind": "port",
+            "sample": f"{d_all} per-graph train steps (one 196-node graph per optimizer step, fp32, torch CPU, {threads} "
+                      f"threads) after 30 warm-up steps",
+            "one_thread": {"value": v_one, "cores": 1, "sample": f"{d_one} steps after 30 warm-up steps"},
+            "host_cpus": os.cpu_count()}
+
+
+# ----------------------------------------------------------------------------------------------- shared pieces
+def timed_region(step, args, world, dev, timer, names, first):
+    """EXACTLY ``args.steps`` steps between barrier + synchronize on both sides; MAX over ranks."""
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.active = True
+    timer.start(names)
     t0 = time.perf_counter()
     host_s = 0.0
+    loss = None
     for i in range(args.steps):
         th = time.perf_counter()
-        loss = step(2 + args.warmup + i)
+        loss = step(first + i)
         host_s += time.perf_counter() - th          # host time to ENQUEUE the step (the GPU runs behind it)
     torch.cuda.synchronize()
     if world > 1:
@@ -173,76 +416,67 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    final_loss = float(loss.detach())
+    return elapsed, host_s, loss
 
+
+def instrumented_pass(step, timer, dev, world, start, steps=3):
+    """Untimed: ``steps`` more steps with EVERY C-ABI launch bracketed by HIP events -> kernel time per class."""
+    torch.cuda.synchronize()
+    timer.start(None)
+    for i in range(steps):
+        step(start + i)
+    torch.cuda.synchronize()
+    rec = timer.stop()
+    if world > 1:
+        dist.barrier()
+    return split_by_class(rec, steps)
+
+
+def base_line(metric, unit, value, world, args, elapsed, dtype):
+    return {"metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": dtype, "data": "synthetic"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", choices=("mil", "gnn"), default="mil")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--bags-per-step", type=int, default=32, help="mil: bags per optimizer step PER GPU")
+    ap.add_argument("--patches", type=int, default=64)
+    ap.add_argument("--image-size", type=int, default=224)
+    ap.add_argument("--radiomics-dim", type=int, default=128)
+    ap.add_argument("--graphs-per-step", type=int, default=256, help="gnn: graphs per optimizer step PER GPU")
+    ap.add_argument("--nodes", type=int, default=196)
+    ap.add_argument("--feat", type=int, default=768)
+    ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--gnn-layers", type=int, default=3)
+    ap.add_argument("--knn-k", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    line = (run_mil if args.config == "mil" else run_gnn)(args, world, rank, dev)
     if rank == 0:
-        n_launch, conv_ms, conv_fl = timer.summary()
-        achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        line = {
-            "metric": "bags/sec (train step) @ 64x224x224 patches/bag",
-            "value": world * B * args.steps / elapsed,
-            "unit": "bags/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "bf16",
-            "data": "synthetic",
-            "config": {"workload": WORKLOAD, "bags_per_step_per_gpu": B, "global_bags_per_step": B * world,
-                       "patches_per_bag": K, "patch": f"3x{S}x{S}", "radiomics_dim": R,
-                       "parallelism": f"dp{world}", "host_enqueue_ms_per_step": host_s * 1e3 / args.steps, "final_loss": final_loss},
-            "roofline": {
-                "bound": "mfma", "kernel": "conv_igemm_kernel (isic_conv2d_igemm_bf16: forward + data-gradient)",
-                "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(B, K, S),
-                "launches": n_launch, "avg_launch_ms": conv_ms / max(n_launch, 1),
-                "algorithmic_gflop_per_launch": conv_fl / max(n_launch, 1) / 1e9,
-                "share_of_step_time": conv_ms * 1e-3 / elapsed,
-            },
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(model, K, S, R, C, args.cpu_budget_s)
+        line["kernel_source_hash"] = kernel_source_hash()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def pmc_traffic(B, K, S):
-    """HBM bytes per conv_igemm launch from the rocprofv3 PMC passes of THIS command, collected offline
-    (counters need their own runs: `tools/collect_traffic.sh`) and committed as profiles/r01_pmc_traffic.json;
-    None when no collection matches the workload."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        d = json.load(open(path))
-        if d.get("bags_per_step") == B and d.get("patches") == K and d.get("image_size") == S:
-            return d["conv_igemm_hbm_bytes_per_launch"]
-    except Exception:
-        pass
-    return None
-
-
-def cpu_baseline(model, K, S, R, C, budget_s):
-    """oracle/ per-bag loop on the host cores (kind "port": the build's CPU restatement of the
-    reference loop; the reference itself cannot travel to the GPU box)."""
-    from oracle import model as omodel
-    p = {k: v.detach().float().cpu().contiguous() for k, v in model.state_dict().items()
-         if v.dtype.is_floating_point and "running_" not in k}
-    threads = torch.get_num_threads()
-    g = torch.Generator().manual_seed(7)
-
-    def make_bag(i):
-        y = i % C
-        return (torch.randn(K, 3, S, S, generator=g) + 0.25 * y, torch.randn(1, R, generator=g) + 0.25 * y, y)
-
-    bps, done = omodel.time_per_bag_train_loop(p, make_bag, n_bags=64, warmup=1, budget_s=budget_s)
-    return {"value": bps, "unit": "bags/s", "cores": threads, "kind": "port",
-            "sample": f"{done} per-bag train steps (1 bag of {K}x3x{S}x{S} per optimizer step, fp32, "
-                      f"torch CPU, {threads} threads) after 1 warm-up step",
-            "host_cpus": os.cpu_count()}
 
 
 if __name__ == "__main__":

@@ -185,9 +185,14 @@ class GraphStore:
         if mode not in GraphBatch.MODES:
             raise ValueError(f"unknown graph mode '{mode}'")
         self.device, self.records, self.mode = device, records, mode
-        self.x = [torch.as_tensor(np.asarray(r["x"], dtype=np.float32)).to(device) for r in records]
+        def dev_tensor(v, dtype, np_dtype):      # records hold numpy arrays (05:248-270) or tensors already in HBM
+            if isinstance(v, torch.Tensor):
+                return v.to(device=device, dtype=dtype)
+            return torch.as_tensor(np.asarray(v, dtype=np_dtype)).to(device)
+
+        self.x = [dev_tensor(r["x"], torch.float32, np.float32) for r in records]
         self.y = np.asarray([int(r["y"]) for r in records])
-        self.ei = [torch.as_tensor(np.asarray(r["edge_index"], dtype=np.int64)).to(device)
+        self.ei = [dev_tensor(r["edge_index"], torch.int64, np.int64)
                    if needs_graph and r.get("edge_index") is not None else None for r in records]
         self.needs_graph = needs_graph
         self._single = {}

@@ -96,13 +96,13 @@ def test_graphstore_mode_and_fold_loop_parity(gnn_type):
     from dataset import synthetic_latent_bags
     from gnn_models import GraphMIL, _GRAPH_MODE
     from isic_hip import train as T
-    bags, labels = synthetic_latent_bags(36, 25, 16, classes=7, shift=0.8, seed=9)
+    bags, labels = synthetic_latent_bags(36, 25, 16, classes=3, shift=0.8, seed=9)
     recs = [{"x": b, "edge_index": bg._knn_edge_index(torch.from_numpy(b), 3).numpy(), "y": int(y)} for b, y in zip(bags, labels)]
     tr, va = recs[:24], recs[24:]
     cfg = dict(gnn_type=gnn_type, gnn_hidden=16, gnn_layers=2, gnn_dropout=0.0, att_dim=8, classifier_dim=12, pool_dropout=0.0)
     torch.manual_seed(3)
     m = GraphMIL(16, gnn_type, 16, 2, 0.0, att_dim=8, att_heads=4, pool_dropout=0.0, classifier_dim=12,
-                 classifier_light=True, num_classes=7)
+                 classifier_light=True, num_classes=3)
     p0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
     m = m.to(DEV)
     store = T.GraphStore(tr, torch.device(DEV), True, mode=_GRAPH_MODE[gnn_type])
@@ -114,8 +114,8 @@ def test_graphstore_mode_and_fold_loop_parity(gnn_type):
     rs = np.random.RandomState(21)
     order = np.random.RandomState(21).permutation(len(tr))
     vm, _, best = T.train_gnn_fold(m, tr, va, va[:4], lr=2e-3, weight_decay=1e-4, epochs=1, graphs_per_step=1,
-                                   num_classes=7, device=torch.device(DEV), rng=rs)
-    p1, ohist = otrain.train_gnn(p0, cfg, tr, va, lr=2e-3, weight_decay=1e-4, epochs=1, orders=[order])
+                                   num_classes=3, device=torch.device(DEV), rng=rs)
+    p1, ohist = otrain.train_gnn(p0, cfg, tr, va, lr=2e-3, weight_decay=1e-4, epochs=1, orders=[order], num_classes=3)
     for k, v in m.state_dict().items():
         assert float((v.cpu() - p1[k]).abs().max()) < 2e-4, k
     assert abs(vm["auc"] - ohist[0]["val_auc"]) <= 0.002
