@@ -94,7 +94,8 @@ class KernelTimer:
                 e0.record()
                 rc = orig(name, *args, stream=stream)
                 e1.record()
-                timer.records.append((name, args, e0, e1))
+                # scalars only: keeping the tensor arguments would pin every activation of the timed region
+                timer.records.append((name, tuple(None if isinstance(a, torch.Tensor) else a for a in args), e0, e1))
                 return rc
             return orig(name, *args, stream=stream)
 
@@ -385,9 +386,13 @@ def cpu_baseline_gnn(model, records, budget_s):
 
     v_all, d_all = run(threads, 30, 400, budget_s / 2)
     v_one, d_one = run(1, 30, 400, budget_s / 2)
-    return {"value": v_all, "unit": "graphs/s", "cores": threads, "kind": "port",
-            "sample": f"{d_all} per-graph train steps (one 196-node graph per optimizer step, fp32, torch CPU, {threads} "
-                      f"threads) after 30 warm-up steps",
+    # these steps are ~100 small ops: more threads are SLOWER (op-dispatch bound), so the headline
+    # CPU figure is the faster setting and both are listed
+    best, cores, done = (v_one, 1, d_one) if v_one >= v_all else (v_all, threads, d_all)
+    return {"value": best, "unit": "graphs/s", "cores": cores, "kind": "port",
+            "sample": f"{done} per-graph train steps (one 196-node graph per optimizer step, fp32, torch CPU, {cores} "
+                      f"thread(s)) after 30 warm-up steps",
+            "all_threads": {"value": v_all, "cores": threads, "sample": f"{d_all} steps after 30 warm-up steps"},
             "one_thread": {"value": v_one, "cores": 1, "sample": f"{d_one} steps after 30 warm-up steps"},
             "host_cpus": os.cpu_count()}
 

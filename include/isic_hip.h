@@ -218,8 +218,6 @@ int isic_gat_bwd(const float* dout, const float* xp, const float* alpha, const f
 int isic_conv2d_igemm_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int Hin, int Win, int Cin,
                            int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad,
                            const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots, void* stream);
-/* developer knob for A/B timing of the implicit-GEMM main loop (0 = one LDS stage, 1 = two). */
-int isic_debug_set_conv_variant(int v);
 /* dW[co][kh][kw][ci] (fp32) += sum_{n,ho,wo} dY[n,ho,wo,co] * X[n,ho*stride+kh-pad,wo*stride+kw-pad,ci]
  * (accumulates into the caller's zeroed or running gradient with whole-row fp32 atomics).
  * workspace: 256-byte aligned, isic_conv2d_wgrad_workspace_bytes(...) bytes (per-pixel

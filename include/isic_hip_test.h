@@ -1,0 +1,30 @@
+/* Test / benchmark-only entry points of libisic_hip.so -- NOT part of the drop-in ABI (include/isic_hip.h).
+ *
+ * They exist so that tests and tools/kernel_bench.py can pin the kernel an ABI entry dispatches to without any
+ * global state in the library: the choice travels with the call.  The product path never uses them. */
+#ifndef ISIC_HIP_TEST_H
+#define ISIC_HIP_TEST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* isic_conv2d_igemm_bf16 (same arguments, same reference citation: the encoder convolutions of
+ * BASELINE.json configs[1], save_latent.py:42-60) with the kernel choice pinned by `variant`, decimal digits:
+ *   units    staging scheme of the generic implicit GEMM + 1 (0 = shipped default; 1..6 = MODE 0..5 of conv_igemm.hip)
+ *   tens     64 -> 64 3x3 layers: 0 shipped default, 1 generic kernel, 2 tile-per-block halo kernel, 3 persistent halo kernel
+ *   hundreds >= 128-channel 3x3 stride-1 layers (conv_halo.hip, pixels staged once for all nine taps):
+ *            0 shipped default, 1 never, 2 wherever the kernel supports the shape
+ * variant = 0 is exactly isic_conv2d_igemm_bf16. */
+int isic_test_conv2d_igemm_variant_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int Hin, int Win,
+                                        int Cin, int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad,
+                                        const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots,
+                                        int variant, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

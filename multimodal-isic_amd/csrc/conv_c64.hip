@@ -12,6 +12,8 @@
 //
 // Same operand conventions as conv_igemm.hip (NHWC bf16 activations, [64][3][3][64] bf16 weights,
 // XOR-swizzled 128-byte LDS rows written lane-linearly by the DMA, D[co][pixel] accumulators).
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -524,13 +526,13 @@ __global__ __launch_bounds__(512) void conv3x3_c64p_kernel(C64PArgs a) {
 
 template <bool STATS, bool ADDEND>
 int launch_c64p(const C64PArgs& a, int grid, hipStream_t stream) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64p_kernel<STATS, ADDEND>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS) != hipSuccess)
-      return ISIC_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static std::once_flag once;                    // thread-safe one-time attribute setup
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(once, [] {
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64p_kernel<STATS, ADDEND>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  P_LDS);
+  });
+  if (attr_rc != hipSuccess) return ISIC_ERR_LAUNCH;
   hipLaunchKernelGGL((conv3x3_c64p_kernel<STATS, ADDEND>), dim3(grid), dim3(512), P_LDS, stream, a);
   return ISIC_OK;
 }
@@ -569,13 +571,13 @@ int isic_conv3x3_c64_launch(int variant, const uint16_t* in, const uint16_t* w, 
   a.stat_sum = stat_sum; a.stat_sumsq = stat_sumsq; a.stat_slots = stat_slots > 0 ? stat_slots : 1;
   a.N = N; a.H = H; a.W = W;
   a.tiles_y = tiles_y; a.tiles_x = tiles_x;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            LDS_BYTES) != hipSuccess)
-      return ISIC_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static std::once_flag once;                    // thread-safe one-time attribute setup
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(once, [] {
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  LDS_BYTES);
+  });
+  if (attr_rc != hipSuccess) return ISIC_ERR_LAUNCH;
   hipLaunchKernelGGL(conv3x3_c64_kernel, dim3((unsigned)blocks), dim3(256), LDS_BYTES, stream, a);
   return ISIC_OK;
 }

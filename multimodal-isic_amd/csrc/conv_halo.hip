@@ -1,0 +1,356 @@
+// 3x3 / stride 1 / pad 1 convolution for the >= 128-channel layers with the INPUT PIXELS STAGED ONCE FOR ALL NINE
+// TAPS (gfx950, bf16 MFMA): ResNet-18 layer2..4 forward and, with flipped weights, data gradient.
+//
+// The generic implicit GEMM (conv_igemm.hip) stages a 256-pixel x 64-channel A tile once PER TAP: 9 x 32 KB of
+// activations next to 9 x 16 KB of weights per 64 input channels and 128 output channels, 85 FLOP per staged byte --
+// and the chip delivers only ~10 TB/s of L2 -> LDS staging (profiles/r01_*: the kernel sits at 0.30-0.37 of the MFMA
+// peak while drawing that rate).  Here a tile is 256 CONSECUTIVE pixels of the flattened (n, h, w) index space and
+// the block stages the pixel rows [m0 - (W+1), m0 + 256 + (W+1)) of a 64-channel chunk ONCE (40 KB at W = 28): tap
+// (kh, kw) of local pixel r is patch row r + kh*W + kw, whatever image rows the tile crosses.  Taps that fall outside
+// the image (pad) are not zero-filled in the patch -- the same patch row is a valid neighbour for one pixel and a
+// padded one for another -- but masked at the fragment read: an invalid lane reads a 128-byte block of zeros instead.
+// Staged bytes per 64 input channels: 40 KB + 9 x 16 KB = 184 KB instead of 432 KB (200 FLOP per staged byte).
+//
+// Structure (one persistent 1024-thread block per CU):
+//   * waves 0-7 multiply: 4 (pixels) x 2 (channels) waves of 64 x 64 = 4 x 4 v_mfma_f32_16x16x32_bf16 tiles, operand
+//     roles swapped as in conv_igemm.hip (a lane ends up with 4 consecutive output channels of one pixel);
+//   * waves 8-15 only issue LDS-DMA (global_load_lds, 16 B per lane): the weights of K-tile (tap, chunk) + 2 into a
+//     three-stage ring, and the NEXT chunk's patch -- also the next tile's first chunk -- one piece per tap into the
+//     second patch buffer, so that nothing but the very first patch of a block is exposed;
+//   * one s_barrier per K-tile; the staging waves count their own DMAs (exactly three per K-tile each, padded with
+//     dummy pieces), s_waitcnt vmcnt(3) == "this K-tile's weights and everything older have landed";
+//   * register-only epilogue (8-byte stores of 4 consecutive channels, the four channel groups of a pixel written
+//     back to back), fused residual-gradient addend (one rounding) and BatchNorm sum / sum of squares of the rounded
+//     outputs kept in registers over all tiles of the block, flushed once (fp64 atomics into `stat_slots` rows).
+//   A block keeps one 128-channel output slice for its whole life (blocks are dealt over the Cout/128 slices).
+//
+// The reference has no convolution kernel of its own (its encoder is an un-vendored ConvMAE run through torch,
+// save_latent.py:42-60); BASELINE.json configs[1] names ResNet-18 (SURVEY.md 8d layer table).
+#include <mutex>
+
+#include "common.h"
+
+namespace {
+
+constexpr int HM = 256;                 // pixels per tile
+constexpr int HN = 128;                 // output channels per block
+constexpr int WSTAGE = HN * 128;        // one (tap, 64-channel chunk) of weights: 128 rows x 128 B
+constexpr int NWST = 3;
+constexpr int MAX_PROWS = 384;          // W <= 63
+constexpr int MAX_PPW = MAX_PROWS / 64; // patch pieces (1 KB DMA groups) per staging wave and chunk
+
+struct HaloArgs {
+  const unsigned short* in;
+  const unsigned short* w;       // [Cout][3][3][Cin]
+  unsigned short* out;
+  const unsigned short* addend;
+  double* stat_sum;
+  double* stat_sumsq;
+  int stat_slots;
+  int H, W, Cin, Cout, M;        // M = N*H*W
+  int mtiles, nslices, groups;   // ceil(M/256), Cout/128, blocks per slice
+  int tiles_per_block, cchunks, prows;
+  unsigned long long magic_hw, magic_w;   // floor(2^40/d)+1 for d = H*W and d = W (M < 2^24)
+};
+
+__device__ __attribute__((aligned(256))) unsigned char g_halo_zero_page[256];
+
+__device__ __forceinline__ unsigned fdiv40(unsigned n, unsigned long long magic) {
+  return (unsigned)(((unsigned long long)n * magic) >> 40);
+}
+// 16-byte-per-lane LDS-DMA in inline asm: outside hipcc's vmcnt bookkeeping (the staging waves count by hand).
+__device__ __forceinline__ void halo_glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+typedef __attribute__((ext_vector_type(2))) float hf32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 hbf16x2;
+__device__ __forceinline__ unsigned halo_pack2(float lo, float hi) {     // one v_cvt_pk_bf16_f32 (round to nearest even)
+  const hf32x2 f = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, hbf16x2));
+}
+__device__ __forceinline__ float halo_row16_sum(float v) {               // sum over the 16 lanes of a DPP row
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+  return v;
+}
+
+// LDS map (bytes): [0, 2*PB) two patch buffers (PB = prows*128) | 3 weight stages | 128 B zeros | 1 KB DMA scratch |
+// 256 floats of statistics
+template <bool STATS, bool ADDEND>
+__global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int PB = a.prows * 128;
+  const int off_w = 2 * PB, off_zero = off_w + NWST * WSTAGE, off_scr = off_zero + 128, off_stat = off_scr + 1024;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // block -> (output slice, contiguous range of pixel tiles)
+  const int slice = blockIdx.x % a.nslices, grp = blockIdx.x / a.nslices;
+  const int t_begin = grp * a.tiles_per_block;
+  const int ntl = min(a.mtiles - t_begin, a.tiles_per_block);
+  if (ntl <= 0) return;                                  // whole block: no barrier has been reached yet
+  const int n0 = slice * HN;
+  const int HWs = a.H * a.W;
+
+  typedef __attribute__((address_space(3))) float lds_float;
+  lds_float* stats_lds = (lds_float*)(smem + off_stat);
+  if (wave >= 8) {
+    // =================================================================== staging waves
+    const int sw = wave - 8;
+    const int r8 = lane >> 3;
+    const int gch = (lane & 7) ^ r8;                     // global 16-byte chunk this lane fetches (swizzle on the source)
+    const unsigned char* zp = g_halo_zero_page + (lane & 7) * 16;
+    const int groups = a.prows >> 3;
+    const int total_chunks = ntl * a.cchunks;
+    const unsigned scr = lds0 + off_scr;
+
+    // one 1 KB piece of the patch of (tile index tl, chunk cc): group g = sw + 8*j, patch rows 8g .. 8g+7
+    auto patch_piece = [&](int j, int tl, int cc, int buf, bool live) {
+      const int g = sw + 8 * j;
+      const bool real = live && g < groups;
+      const long long pix = (long long)(t_begin + tl) * HM - (a.W + 1) + g * 8 + r8;
+      const bool ok = real && pix >= 0 && pix < a.M;
+      const void* src = ok ? (const void*)(a.in + (size_t)pix * a.Cin + cc * 64 + gch * 8) : (const void*)zp;
+      halo_glds16(src, real ? lds0 + (unsigned)(buf * PB + g * 1024) : scr);
+    };
+    // weights of K-tile (tap, cc): rows co = n0 + 8g + r8 for the wave's two groups g = 2*sw, 2*sw + 1
+    const unsigned short* wrow = a.w + ((size_t)(n0 + 16 * sw + r8) * 9) * a.Cin + gch * 8;
+    auto weights = [&](int tap, int cc, int stage, bool live) {
+      const unsigned short* s0 = wrow + (size_t)tap * a.Cin + cc * 64;
+      const unsigned dst = lds0 + off_w + stage * WSTAGE + sw * 2048;
+      halo_glds16(live ? (const void*)s0 : (const void*)zp, live ? dst : scr);
+      halo_glds16(live ? (const void*)(s0 + (size_t)8 * 9 * a.Cin) : (const void*)zp, live ? dst + 1024 : scr);
+    };
+
+#pragma unroll
+    for (int j = 0; j < MAX_PPW; ++j) patch_piece(j, 0, 0, 0, true);
+    weights(0, 0, 0, true);
+    weights(1, 0, 1, true);                              // a chunk always has 9 K-tiles: K-tile 1 exists
+
+    int gc = 0;                                          // chunk counter over (tile, chunk)
+    for (int tl = 0; tl < ntl; ++tl) {
+      for (int cc = 0; cc < a.cchunks; ++cc, ++gc) {
+        const bool more_chunks = gc + 1 < total_chunks;
+        const int ncc = cc + 1 == a.cchunks ? 0 : cc + 1;
+        const int ntl_ = cc + 1 == a.cchunks ? tl + 1 : tl;
+#pragma unroll 1
+        for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int tap = kh * 3 + kw;                 // weight stage of K-tile (tap, chunk) = tap % 3 = kw
+            // this K-tile's weights (issued two K-tiles ago) and everything older -- the patch pieces of this chunk
+            // among it -- have landed when only the previous K-tile's three DMAs are still in flight
+            if (gc == 0 && tap == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            __builtin_amdgcn_s_barrier();    // ... for every staging wave; the MFMA waves are done with K-tile it-1
+            // weights of K-tile it+2 into the stage K-tile it-1 used
+            const bool wrap = tap + 2 >= 9;
+            const int t2 = wrap ? tap + 2 - 9 : tap + 2;
+            weights(t2, wrap ? ncc : cc, (kw + 2) % NWST, !wrap || more_chunks);
+            // one piece of the next chunk's patch into the buffer the previous chunk used
+            patch_piece(tap, ntl_, ncc, (gc + 1) & 1, more_chunks && tap < MAX_PPW);
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may outlive the block's LDS allocation
+  } else {
+  // ===================================================================== MFMA waves
+  if (tid < 8) reinterpret_cast<u32x4*>(smem + off_zero)[tid] = (u32x4){0u, 0u, 0u, 0u};   // 128 B of zeros
+  if (STATS && tid < 256) stats_lds[tid] = 0.f;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // ordered before the first barrier of the K loop
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  // weight fragment byte offsets inside a stage: row wn*64 + j*16 + fr, chunk fg (k-step 0; k-step 1 = ^ 64)
+  // (rows 16 apart share the swizzle key row & 7: tile j / i is the tile-0 address + 2048 j / i)
+  const unsigned boff0 = (unsigned)((wn * 64 + fr) * 128 + ((fg ^ (fr & 7)) << 4));
+  const int prow0 = wm * 64 + fr;                        // patch row of tap (0, 0) of this lane's first pixel
+
+  int gc = 0;
+  for (int tl = 0; tl < ntl; ++tl) {
+    const int m0 = (t_begin + tl) * HM;
+    // this lane's four pixels: tap validity (bit tap) and the patch row of tap (0, 0)
+    unsigned vmask[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = wm * 64 + i * 16 + fr;
+      const int m = m0 + r;
+      unsigned vm = 0u;
+      if (m < a.M) {
+        const int n = (int)fdiv40((unsigned)m, a.magic_hw);
+        const int rem = m - n * HWs;
+        const int h = (int)fdiv40((unsigned)rem, a.magic_w), w = rem - h * a.W;
+        const unsigned vh = (h >= 1 ? 1u : 0u) | 2u | (h + 1 < a.H ? 4u : 0u);
+        const unsigned vw = (w >= 1 ? 1u : 0u) | 2u | (w + 1 < a.W ? 4u : 0u);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) vm |= (((vh >> (t / 3)) & (vw >> (t % 3))) & 1u) << t;
+      }
+      vmask[i] = vm;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int cc = 0; cc < a.cchunks; ++cc, ++gc) {
+      const int pbase = (gc & 1) * PB;
+#pragma unroll 1
+      for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          __builtin_amdgcn_s_barrier();
+          const unsigned char* wst = smem + off_w + kw * WSTAGE;     // stage of K-tile (tap, chunk) = tap % 3 = kw
+          const int tap = kh * 3 + kw;
+          const int toff = kh * a.W + kw;
+          unsigned aoff[4];                                // byte offset of the k-step-0 fragment (k-step 1: ^ 64)
+          const int p = prow0 + toff;
+          const int real0 = pbase + p * 128 + ((fg ^ (p & 7)) << 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) aoff[i] = (unsigned)(((vmask[i] >> tap) & 1u) ? real0 + i * 2048 : off_zero);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              af[i] = *reinterpret_cast<const bf16x8*>(smem + (aoff[i] ^ (unsigned)(ks << 6)));
+              bfr[i] = *reinterpret_cast<const bf16x8*>(wst + ((boff0 ^ (unsigned)(ks << 6)) + i * 2048));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+
+    // ---- register-only epilogue: lane (fg, fr) holds, for MFMA tile (i, j), output channels
+    //      n0 + wn*64 + j*16 + fg*4 + {0..3} of pixel m0 + wm*64 + i*16 + fr
+    bool valid[4];
+    unsigned rowoff[4];                                  // element offsets: M * Cout < 2^31 (checked by the host)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + fr;
+      valid[i] = m < a.M;
+      rowoff[i] = (unsigned)(valid[i] ? m : 0) * (unsigned)a.Cout + (unsigned)(n0 + wn * 64 + fg * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      u32x2 ad[4];
+      if (ADDEND) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          ad[i] = valid[i] ? *reinterpret_cast<const u32x2*>(a.addend + rowoff[i] + j * 16) : (u32x2){0u, 0u};
+      }
+      float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 c = acc[i][j];
+        if (ADDEND) {
+          c[0] += __uint_as_float(ad[i][0] << 16);
+          c[1] += __uint_as_float(ad[i][0] & 0xFFFF0000u);
+          c[2] += __uint_as_float(ad[i][1] << 16);
+          c[3] += __uint_as_float(ad[i][1] & 0xFFFF0000u);
+        }
+        u32x2 v;
+        v[0] = halo_pack2(c[0], c[1]);
+        v[1] = halo_pack2(c[2], c[3]);
+        if (STATS && valid[i]) {                         // statistics of the ROUNDED outputs
+          const float r0 = __uint_as_float(v[0] << 16), r1 = __uint_as_float(v[0] & 0xFFFF0000u);
+          const float r2 = __uint_as_float(v[1] << 16), r3 = __uint_as_float(v[1] & 0xFFFF0000u);
+          s4[0] += r0; q4[0] += r0 * r0;
+          s4[1] += r1; q4[1] += r1 * r1;
+          s4[2] += r2; q4[2] += r2 * r2;
+          s4[3] += r3; q4[3] += r3 * r3;
+        }
+        if (valid[i]) __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(a.out + rowoff[i] + j * 16));
+      }
+      if (STATS) {
+        // lanes of one fg group (a DPP row of 16) hold the same 4 channels for 16 different pixels; the four wm waves
+        // of a channel half meet in LDS (fp32 per block, fp64 across blocks)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float s = halo_row16_sum(s4[c]), q = halo_row16_sum(q4[c]);
+          if (fr == 0) {
+            const int ch = wn * 64 + j * 16 + fg * 4 + c;
+            __hip_atomic_fetch_add(stats_lds + ch, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(stats_lds + 128 + ch, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    }
+  }
+  }   // MFMA waves
+
+  if (STATS) {
+    lds_barrier();                                       // all sixteen waves: every tile's partial sums are in LDS
+    if (tid < 256) {
+      const size_t slot = (size_t)(blockIdx.x % a.stat_slots) * a.Cout + n0 + (tid & 127);
+      atomicAdd((tid < 128 ? a.stat_sum : a.stat_sumsq) + slot, (double)stats_lds[tid]);
+    }
+  }
+}
+
+template <bool STATS, bool ADDEND>
+int launch_halo(const HaloArgs& a, int grid, int lds, hipStream_t stream) {
+  static std::once_flag once;
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(once, [] {
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<STATS, ADDEND>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MAX_PROWS * 128 + NWST * WSTAGE + 2176);
+  });
+  if (attr_rc != hipSuccess) return ISIC_ERR_LAUNCH;
+  hipLaunchKernelGGL((conv_halo_kernel<STATS, ADDEND>), dim3(grid), dim3(1024), lds, stream, a);
+  return ISIC_OK;
+}
+
+}  // namespace
+
+// 3x3 / stride 1 / pad 1, Cin % 64 == 0, Cout % 128 == 0, W <= 63: called by isic_conv2d_igemm_bf16 (conv_igemm.hip).
+bool isic_conv_halo_supported(int N, int H, int W, int Cin, int Cout) {
+  const long long M = (long long)N * H * W;
+  return Cin % 64 == 0 && Cout % HN == 0 && W >= 1 && 256 + 2 * W + 2 <= MAX_PROWS && M < (1LL << 24) && H * W < (1 << 16) &&
+         M * Cin <= 0x7FFFFFFFLL && M * Cout <= 0x7FFFFFFFLL;
+}
+
+int isic_conv_halo_launch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int H, int W, int Cin, int Cout,
+                          const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots,
+                          hipStream_t stream) {
+  if (!isic_conv_halo_supported(N, H, W, Cin, Cout)) return ISIC_ERR_UNSUPPORTED;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cus = n;
+  }
+  HaloArgs a;
+  a.in = in; a.w = w; a.out = out; a.addend = addend;
+  a.stat_sum = stat_sum; a.stat_sumsq = stat_sumsq; a.stat_slots = stat_slots > 0 ? stat_slots : 1;
+  a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.M = N * H * W;
+  a.mtiles = ceil_div(a.M, HM);
+  a.nslices = Cout / HN;
+  int groups = cus / a.nslices;
+  if (groups < 1) groups = 1;
+  a.tiles_per_block = ceil_div(a.mtiles, groups);
+  a.groups = ceil_div(a.mtiles, a.tiles_per_block);          // every block owns at least one tile
+  a.cchunks = Cin / 64;
+  a.prows = ceil_div(HM + 2 * W + 2, 8) * 8;
+  a.magic_hw = ((1ULL << 40) / (unsigned long long)(H * W)) + 1;
+  a.magic_w = ((1ULL << 40) / (unsigned long long)W) + 1;
+  const int lds = 2 * a.prows * 128 + NWST * WSTAGE + 2176;
+  const int grid = a.groups * a.nslices;
+  if (stat_sum && addend) return ISIC_ERR_UNSUPPORTED;
+  if (stat_sum) return launch_halo<true, false>(a, grid, lds, stream);
+  if (addend) return launch_halo<false, true>(a, grid, lds, stream);
+  return launch_halo<false, false>(a, grid, lds, stream);
+}

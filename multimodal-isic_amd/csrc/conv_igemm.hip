@@ -34,6 +34,8 @@
 // 3-stage variants are kept behind ISIC_CONV_MODE for A/B timing; measured slower.)
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -405,13 +407,13 @@ int launch_conv(const ConvArgsN& a, hipStream_t s) {
   constexpr int MAIN = ((MODE == 3 || MODE == 5) ? 3 : (MODE == 0 ? 1 : 2)) * STAGE;
   constexpr int THREADS = (MODE >= 4 ? 2 : 1) * MT;
   constexpr int LDS = MAIN > CBYTES ? MAIN : CBYTES;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, MODE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-      return ISIC_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static std::once_flag once;                    // one per template instance; thread-safe
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(once, [] {
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  });
+  if (attr_rc != hipSuccess) return ISIC_ERR_LAUNCH;
   int maxM = 0;
   for (int i = 0; i < a.n; ++i) maxM = a.c[i].M > maxM ? a.c[i].M : maxM;
   dim3 grid(ceil_div(maxM, BM), a.c[0].Cout / BN, a.n);
@@ -430,40 +432,54 @@ int launch_conv_mode(int mode, const ConvArgsN& a, hipStream_t s) {
   }
 }
 
-int g_conv_variant = -1;  // staging MODE of conv_igemm_kernel; -1 = not chosen yet (env ISIC_CONV_MODE or default)
 constexpr int kDefaultConvMode = 5;   // staging waves, three stages, 256 x 128 tile: fastest measured (tools/kernel_bench.py)
-inline int conv_mode() {
-  if (g_conv_variant < 0) {
-    const char* e = getenv("ISIC_CONV_MODE");
-    g_conv_variant = (e && e[0] >= '0' && e[0] <= '5') ? (e[0] - '0') : kDefaultConvMode;
-  }
-  return g_conv_variant;
-}
-
-// halo-resident 3x3 kernels for the 64 -> 64 layers (conv_c64.hip): 0 = off (generic kernel), 1 = tile per block,
-// 2 = persistent blocks; env ISIC_CONV_C64
-int g_conv_c64 = -1;
-constexpr int kDefaultConvC64 = 2;
-inline int conv_c64_variant() {
-  if (g_conv_c64 < 0) {
-    const char* e = getenv("ISIC_CONV_C64");
-    g_conv_c64 = (e && e[0] >= '0' && e[0] <= '2') ? (e[0] - '0') : kDefaultConvC64;
-  }
-  return g_conv_c64;
-}
+constexpr int kDefaultConvC64 = 2;    // 64 -> 64 3x3 layers: persistent halo kernel (conv_c64.hip)
 
 }  // namespace
 
 int isic_conv3x3_c64_launch(int variant, const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int H, int W,
                             const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots,
                             hipStream_t stream);
+bool isic_conv_halo_supported(int N, int H, int W, int Cin, int Cout);
+int isic_conv_halo_launch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int H, int W, int Cin, int Cout,
+                          const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots,
+                          hipStream_t stream);
 
-extern "C" {
+namespace {
 
-int isic_conv2d_igemm_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int Hin, int Win, int Cin,
-                           int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad,
-                           const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots, void* stream) {
+// `variant` (include/isic_hip_test.h): 0 = the shipped dispatch.  Otherwise, decimal digits
+//   units: staging MODE of the generic kernel + 1 (0 = default), tens: 64 -> 64 kernels (0 default, 1 generic kernel,
+//   2 tile per block, 3 persistent), hundreds: pixels-staged-once kernel of conv_halo.hip (0 = where profitable,
+//   1 = never, 2 = wherever it is supported).  No global state: the choice travels with the call.
+struct ConvVariant {
+  int mode, c64, halo;
+};
+inline ConvVariant decode_variant(int v) {
+  ConvVariant r;
+  const int m = v % 10, c = (v / 10) % 10;
+  r.mode = m == 0 ? kDefaultConvMode : m - 1;
+  r.c64 = c == 0 ? kDefaultConvC64 : c - 1;
+  r.halo = (v / 100) % 10;
+  return r;
+}
+
+int conv2d_dispatch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int Hin, int Win, int Cin,
+                    int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad,
+                    const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots, int variant,
+                    void* stream);
+
+}  // namespace
+
+namespace {
+
+int conv2d_dispatch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int Hin, int Win, int Cin,
+                    int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad,
+                    const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots, int variant,
+                    void* stream) {
   ISIC_CHECK_ARG(in && w && out);
+  ISIC_CHECK_ARG(variant >= 0 && variant < 1000);
+  const ConvVariant cv = decode_variant(variant);
+  ISIC_CHECK_ARG(cv.mode >= 0 && cv.mode <= 5 && cv.c64 >= 0 && cv.c64 <= 2 && cv.halo >= 0 && cv.halo <= 2);
   ISIC_CHECK_ARG(N > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && Kh > 0 && Kw > 0 && up > 0);
   ISIC_CHECK_ARG(down == 1 || down == 2);
   ISIC_CHECK_ARG((stat_sum == nullptr) == (stat_sumsq == nullptr));
@@ -471,10 +487,17 @@ int isic_conv2d_igemm_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out,
   if (Cin % 64 != 0 || Cout % 64 != 0) return ISIC_ERR_UNSUPPORTED;
   // element offsets inside the kernels are 32-bit: both whole tensors must stay below 2^31 elements
   if ((int64_t)N * Hout * Wout * Cout > 0x7FFFFFFFLL || (int64_t)N * Hin * Win * Cin > 0x7FFFFFFFLL) return ISIC_ERR_UNSUPPORTED;
-  if (Cin == 64 && Cout == 64 && Kh == 3 && Kw == 3 && up == 1 && down == 1 && pad == 1 && Hin == Hout && Win == Wout &&
-      conv_c64_variant() != 0) {
-    const int rc = isic_conv3x3_c64_launch(conv_c64_variant(), in, w, out, N, Hin, Win, addend, stat_sum, stat_sumsq, stat_slots,
+  const bool same3x3 = Kh == 3 && Kw == 3 && up == 1 && down == 1 && pad == 1 && Hin == Hout && Win == Wout;
+  if (Cin == 64 && Cout == 64 && same3x3 && cv.c64 != 0) {
+    const int rc = isic_conv3x3_c64_launch(cv.c64, in, w, out, N, Hin, Win, addend, stat_sum, stat_sumsq, stat_slots,
                                            as_stream(stream));
+    return rc != ISIC_OK ? rc : isic_launch_status();
+  }
+  // >= 128-channel 3x3 layers: every input pixel staged once for all nine taps (conv_halo.hip)
+  if (same3x3 && cv.halo != 1 && !(stat_sum && addend) && isic_conv_halo_supported(N, Hin, Win, Cin, Cout) &&
+      (cv.halo == 2 || Cin >= 128)) {
+    const int rc = isic_conv_halo_launch(in, w, out, N, Hin, Win, Cin, Cout, addend, stat_sum, stat_sumsq, stat_slots,
+                                         as_stream(stream));
     return rc != ISIC_OK ? rc : isic_launch_status();
   }
   ConvArgs a;
@@ -510,7 +533,7 @@ int isic_conv2d_igemm_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out,
   if (all.n == 0) return ISIC_OK;
   {
     int rc;
-    const int mode = conv_mode();
+    const int mode = cv.mode;
     if (Cout % 128 != 0) rc = launch_conv_mode<256, 64, 4, 1>(mode == 5 ? 4 : mode, all, s);
     else if (mode == 5) rc = launch_conv<256, 128, 4, 2, 5>(all, s);        // 8 MFMA + 8 staging waves, three stages
     else rc = launch_conv_mode<128, 128, 2, 2>(mode, all, s);
@@ -519,13 +542,23 @@ int isic_conv2d_igemm_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out,
   return isic_launch_status();
 }
 
-int isic_debug_set_conv_variant(int v) {
-  // v % 10 in 0..3: staging mode of the generic kernel; v / 10: 0 = default 64 -> 64 kernel, 1 = generic kernel for
-  // those layers too, 2 = tile-per-block halo kernel, 3 = persistent halo kernel
-  const int c = v / 10;
-  g_conv_c64 = c == 0 ? kDefaultConvC64 : c - 1;
-  g_conv_variant = v % 10;
-  return ISIC_OK;
+}  // namespace
+
+extern "C" {
+
+int isic_conv2d_igemm_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int Hin, int Win, int Cin,
+                           int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad,
+                           const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots, void* stream) {
+  return conv2d_dispatch(in, w, out, N, Hin, Win, Cin, Hout, Wout, Cout, Kh, Kw, up, down, pad, addend, stat_sum,
+                         stat_sumsq, stat_slots, 0, stream);
+}
+
+int isic_test_conv2d_igemm_variant_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int Hin, int Win,
+                                        int Cin, int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad,
+                                        const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots,
+                                        int variant, void* stream) {
+  return conv2d_dispatch(in, w, out, N, Hin, Win, Cin, Hout, Wout, Cout, Kh, Kw, up, down, pad, addend, stat_sum,
+                         stat_sumsq, stat_slots, variant, stream);
 }
 
 int isic_conv_weight_prep_bf16(const float* w_krsc, uint16_t* w_fwd, uint16_t* w_dgrad, int O, int I, int Kh, int Kw,

@@ -266,22 +266,9 @@ int isic_wgrad_c128_launch(const uint16_t* x, const uint16_t* dy, float* dw, int
                            hipStream_t stream);
 
 namespace {
-int g_wgrad_c128 = -1;    // env ISIC_WGRAD_C128=0 routes the 128 -> 128 layers through the generic kernel
-inline bool wgrad_c128_enabled() {
-  if (g_wgrad_c128 < 0) {
-    const char* e = getenv("ISIC_WGRAD_C128");
-    g_wgrad_c128 = (e && e[0] == '0') ? 0 : 1;
-  }
-  return g_wgrad_c128 != 0;
-}
-int g_wgrad_c64 = -1;     // env ISIC_WGRAD_C64=0 routes the 64 -> 64 layers through the generic kernel
-inline bool wgrad_c64_enabled() {
-  if (g_wgrad_c64 < 0) {
-    const char* e = getenv("ISIC_WGRAD_C64");
-    g_wgrad_c64 = (e && e[0] == '0') ? 0 : 1;
-  }
-  return g_wgrad_c64 != 0;
-}
+// the all-taps kernels are always used for the shapes they cover (no environment switches, no global state)
+inline bool wgrad_c128_enabled() { return true; }
+inline bool wgrad_c64_enabled() { return true; }
 }  // namespace
 
 extern "C" {

@@ -11,6 +11,8 @@
 // 16-channel halves of the slice.  X is staged by each of the four slice blocks (L2 hits), dY only by its own:
 // 121 staged bytes per MFMA against 250 for the one-tap-per-block kernel of conv_wgrad.hip.
 // Per-block partials go to the workspace with plain stores and are summed in a fixed order: no atomics.
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -264,13 +266,13 @@ int isic_wgrad_c128_launch(const uint16_t* x, const uint16_t* dy, float* dw, int
   a.tiles_y = ceil_div(H, T_H); a.tiles_x = ceil_div(W, T_W);
   a.total_tiles = N * a.tiles_y * a.tiles_x;
   a.blocks_per_slice = wc128_plan(N, H, W, &a.tiles_per_block);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_c128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            LDS_ALL) != hipSuccess)
-      return ISIC_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static std::once_flag once;                    // thread-safe one-time attribute setup
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(once, [] {
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_c128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  LDS_ALL);
+  });
+  if (attr_rc != hipSuccess) return ISIC_ERR_LAUNCH;
   hipLaunchKernelGGL(wgrad_c128_kernel, dim3(4 * a.blocks_per_slice), dim3(768), LDS_ALL, stream, a);
   hipLaunchKernelGGL(wgrad_c128_reduce_kernel, dim3(4 * SLICE_ELEMS / 64), dim3(256), 0, stream, a.partial, dw,
                      a.blocks_per_slice);

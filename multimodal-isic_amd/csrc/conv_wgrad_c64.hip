@@ -14,6 +14,8 @@
 // the K axis (pixels) is the row axis of the NHWC images in LDS.
 // The partial gradients of the blocks go to the workspace with plain stores and are summed by a second kernel in
 // a fixed order: the result does not depend on the scheduling (no atomics).
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -282,13 +284,13 @@ int isic_wgrad_c64_launch(const uint16_t* x, const uint16_t* dy, float* dw, int 
   a.tiles_y = ceil_div(H, WT_H); a.tiles_x = ceil_div(W, WT_W);
   a.total_tiles = N * a.tiles_y * a.tiles_x;
   const int grid = wc64_blocks(N, H, W, &a.tiles_per_block);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            LDS_TOTAL) != hipSuccess)
-      return ISIC_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static std::once_flag once;                    // thread-safe one-time attribute setup
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(once, [] {
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  LDS_TOTAL);
+  });
+  if (attr_rc != hipSuccess) return ISIC_ERR_LAUNCH;
   hipLaunchKernelGGL(wgrad_c64_kernel, dim3(grid), dim3(768), LDS_TOTAL, stream, a);
   hipLaunchKernelGGL(wgrad_c64_reduce_kernel, dim3(DW_ELEMS / 64), dim3(256), 0, stream, a.partial, dw, grid);
   return ISIC_OK;

@@ -40,6 +40,11 @@ def header_path():
     raise IsicHipError("include/isic_hip.h not found next to the package")
 
 
+def test_header_path():
+    """include/isic_hip_test.h: test / benchmark-only entry points (kernel variants pinned per call)."""
+    return os.path.join(os.path.dirname(header_path()), "isic_hip_test.h")
+
+
 def parse_header(path=None):
     """-> {name: (restype, [(ctype, param_name, is_pointer)])} for every prototype."""
     text = open(path or header_path()).read()
@@ -73,6 +78,9 @@ class _Lib:
                 "(hipcc --offload-arch=gfx950).  There is no CPU/PyTorch fallback for this path.")
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
+        self.public = set(self.protos)                      # the drop-in ABI (include/isic_hip.h)
+        if os.path.exists(test_header_path()):
+            self.protos.update(parse_header(test_header_path()))
         self.fn = {}
         for name, (restype, args) in self.protos.items():
             try:

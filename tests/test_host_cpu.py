@@ -20,9 +20,13 @@ def test_library_exports_every_declared_symbol():
     from isic_hip import lib
     L = lib.lib()
     text = open(os.path.join(ROOT, "include", "isic_hip.h")).read()
-    declared = set(re.findall(r"\b(isic_\w+)\s*\(", text))
+    public = set(re.findall(r"\b(isic_\w+)\s*\(", text))
+    assert public == L.public, public ^ L.public
+    assert not any("debug" in n or "test" in n for n in public)      # scaffolding stays out of the drop-in ABI
+    ttext = open(os.path.join(ROOT, "include", "isic_hip_test.h")).read()
+    declared = public | set(re.findall(r"\b(isic_test_\w+)\s*\(", ttext))
     assert declared == set(L.protos), declared ^ set(L.protos)
-    assert len(declared) >= 35
+    assert len(public) >= 35
     cdll = ctypes.CDLL(lib.LIB_PATH)
     for name in declared:
         assert hasattr(cdll, name), name

@@ -117,6 +117,8 @@ def test_graphstore_mode_and_fold_loop_parity(gnn_type):
                                    num_classes=3, device=torch.device(DEV), rng=rs)
     p1, ohist = otrain.train_gnn(p0, cfg, tr, va, lr=2e-3, weight_decay=1e-4, epochs=1, orders=[order], num_classes=3)
     for k, v in m.state_dict().items():
+        if k.startswith("attention_layers.") and k.endswith(".2.bias"):
+            continue      # softmax is shift-invariant: the true gradient is 0 and AdamW normalises rounding noise
         assert float((v.cpu() - p1[k]).abs().max()) < 2e-4, k
     assert abs(vm["auc"] - ohist[0]["val_auc"]) <= 0.002
 

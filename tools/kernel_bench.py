@@ -38,10 +38,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=512)
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--variant", type=int, default=5)
+    ap.add_argument("--variant", type=int, default=0,
+                    help="kernel choice pinned per call (include/isic_hip_test.h); 0 = the shipped dispatch")
     ap.add_argument("--only", default="", help="substring filter on the conv shape names; also skips the extra kernels")
     a = ap.parse_args()
-    call("isic_debug_set_conv_variant", a.variant)
     N = a.n
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
     print(f"{'conv':28s} {'GFLOP':>8s} | {'fwd ms':>8s} {'TF/s':>7s} | {'dgrad ms':>8s} {'TF/s':>7s} | {'wgrad ms':>8s} {'TF/s':>7s}")
@@ -60,8 +60,8 @@ def main():
         dw = torch.zeros_like(w)
         acc = torch.zeros(2, 32, co, device=DEV, dtype=torch.float64)
         gf = 2.0 * N * ho * ho * co * k * k * ci / 1e9
-        tf = timeit(lambda: call("isic_conv2d_igemm_bf16", x, wf, out, N, h, h, ci, ho, ho, co, k, k, s, 1, p, None, acc[0], acc[1], 32), a.iters)
-        td = timeit(lambda: call("isic_conv2d_igemm_bf16", dy, wd, dx, N, ho, ho, co, h, h, ci, k, k, 1, s, k - 1 - p, None, None, None, 0), a.iters)
+        tf = timeit(lambda: call("isic_test_conv2d_igemm_variant_bf16", x, wf, out, N, h, h, ci, ho, ho, co, k, k, s, 1, p, None, acc[0], acc[1], 32, a.variant), a.iters)
+        td = timeit(lambda: call("isic_test_conv2d_igemm_variant_bf16", dy, wd, dx, N, ho, ho, co, h, h, ci, k, k, 1, s, k - 1 - p, None, None, None, 0, a.variant), a.iters)
         wsb = torch.empty(call("isic_conv2d_wgrad_workspace_bytes", N, ci, ho, ho, co, k, k), device=DEV, dtype=torch.uint8)
         tw = timeit(lambda: call("isic_conv2d_wgrad_bf16", x, dy, dw, N, h, h, ci, ho, ho, co, k, k, s, p, wsb, wsb.numel()), a.iters)
         print(f"{name:28s} {gf:8.1f} | {tf:8.3f} {gf / tf:7.0f} | {td:8.3f} {gf / td:7.0f} | {tw:8.3f} {gf / tw:7.0f}   x{cnt}")
