@@ -310,7 +310,7 @@ def run_gnn(args, world, rank, dev):
         opt.zero_grad()
         sync.reset()
         probs, _ = model(xb, offsets=ob, graph=gb)
-        loss = ops.cross_entropy_from_probs(probs, torch.as_tensor(store.y[idx], device=dev))
+        loss = ops.cross_entropy_from_probs(probs, store.y_dev[torch.as_tensor(idx, device=dev)])
         loss.backward()
         sync.finish()
         opt.step(grad_scale=1.0 / world)

@@ -19,9 +19,10 @@
 //     second patch buffer, so that nothing but the very first patch of a block is exposed;
 //   * one s_barrier per K-tile; the staging waves count their own DMAs (exactly three per K-tile each, padded with
 //     dummy pieces), s_waitcnt vmcnt(3) == "this K-tile's weights and everything older have landed";
-//   * register-only epilogue (8-byte stores of 4 consecutive channels, the four channel groups of a pixel written
-//     back to back), fused residual-gradient addend (one rounding) and BatchNorm sum / sum of squares of the rounded
-//     outputs kept in registers over all tiles of the block, flushed once (fp64 atomics into `stat_slots` rows).
+//   * register-only epilogue: the weight rows are permuted inside a stage so that a lane ends up with EIGHT consecutive
+//     output channels (16-byte stores, 64 contiguous bytes per pixel and instruction); fused residual-gradient addend
+//     (all loads before the first store, one rounding) and BatchNorm sum / sum of squares of the rounded outputs,
+//     summed per block in LDS and flushed once (fp64 atomics into `stat_slots` rows).
 //   A block keeps one 128-channel output slice for its whole life (blocks are dealt over the Cout/128 slices).
 //
 // The reference has no convolution kernel of its own (its encoder is an un-vendored ConvMAE run through torch,
@@ -118,13 +119,17 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
       const void* src = ok ? (const void*)(a.in + (size_t)pix * a.Cin + cc * 64 + gch * 8) : (const void*)zp;
       halo_glds16(src, real ? lds0 + (unsigned)(buf * PB + g * 1024) : scr);
     };
-    // weights of K-tile (tap, cc): rows co = n0 + 8g + r8 for the wave's two groups g = 2*sw, 2*sw + 1
-    const unsigned short* wrow = a.w + ((size_t)(n0 + 16 * sw + r8) * 9) * a.Cin + gch * 8;
+    // weights of K-tile (tap, cc): stage rows sr = 16*sw + 8*t + r8 (t = 0, 1: the wave's two DMA groups).  Stage row
+    // wn*64 + j*16 + rho feeds row rho of MFMA tile j of channel half wn and holds output channel
+    //   wn*64 + 32*(j>>1) + 8*(rho>>2) + 4*(j&1) + (rho&3)
+    // so that a lane's results of tiles 2t, 2t+1 are EIGHT CONSECUTIVE channels (one 16-byte store per pixel).
+    const int chan0 = (sw >> 2) * 64 + ((sw & 3) >> 1) * 32 + (r8 >> 2) * 8 + (sw & 1) * 4 + (r8 & 3);   // t = 0; t = 1: + 16
+    const unsigned short* wrow = a.w + ((size_t)(n0 + chan0) * 9) * a.Cin + gch * 8;
     auto weights = [&](int tap, int cc, int stage, bool live) {
       const unsigned short* s0 = wrow + (size_t)tap * a.Cin + cc * 64;
       const unsigned dst = lds0 + off_w + stage * WSTAGE + sw * 2048;
       halo_glds16(live ? (const void*)s0 : (const void*)zp, live ? dst : scr);
-      halo_glds16(live ? (const void*)(s0 + (size_t)8 * 9 * a.Cin) : (const void*)zp, live ? dst + 1024 : scr);
+      halo_glds16(live ? (const void*)(s0 + (size_t)16 * 9 * a.Cin) : (const void*)zp, live ? dst + 1024 : scr);
     };
 
 #pragma unroll
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
       const int pbase = (gc & 1) * PB;
 #pragma unroll 1
       for (int kh = 0; kh < 3; ++kh) {
-#pragma unroll
+#pragma unroll 1
         for (int kw = 0; kw < 3; ++kw) {
           __builtin_amdgcn_s_barrier();
           const unsigned char* wst = smem + off_w + kw * WSTAGE;     // stage of K-tile (tap, chunk) = tap % 3 = kw
@@ -232,60 +237,75 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
       }
     }
 
-    // ---- register-only epilogue: lane (fg, fr) holds, for MFMA tile (i, j), output channels
-    //      n0 + wn*64 + j*16 + fg*4 + {0..3} of pixel m0 + wm*64 + i*16 + fr
-    bool valid[4];
-    unsigned rowoff[4];                                  // element offsets: M * Cout < 2^31 (checked by the host)
+    // ---- register-only epilogue: lane (fg, fr) holds, for MFMA tiles (i, 2t) and (i, 2t+1), the eight consecutive
+    //      output channels n0 + wn*64 + 32t + 8fg + {0..7} of pixel m0 + wm*64 + i*16 + fr: one 16-byte access each.
+    //      Every addend load is issued before the first store (vmcnt counts loads and stores in order: a load behind
+    //      a store would wait for the store's round trip), and nothing behind the stores waits on vmcnt.
+    const unsigned chan = (unsigned)(n0 + wn * 64 + fg * 8);
+    u32x4 ad[4][2];
+    if (ADDEND) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + fr;
+        const unsigned off = (unsigned)(m < a.M ? m : 0) * (unsigned)a.Cout + chan;     // M * Cout < 2^31 (host check)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) ad[i][t] = *reinterpret_cast<const u32x4*>(a.addend + off + t * 32);
+      }
+    }
+    float s8[2][8], q8[2][8];
+    if (STATS) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { s8[t][c] = 0.f; q8[t][c] = 0.f; }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + wm * 64 + i * 16 + fr;
-      valid[i] = m < a.M;
-      rowoff[i] = (unsigned)(valid[i] ? m : 0) * (unsigned)a.Cout + (unsigned)(n0 + wn * 64 + fg * 4);
-    }
+      const bool valid = m < a.M;
+      const unsigned off = (unsigned)(valid ? m : 0) * (unsigned)a.Cout + chan;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      u32x2 ad[4];
-      if (ADDEND) {
+      for (int t = 0; t < 2; ++t) {
+        u32x4 v;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          ad[i] = valid[i] ? *reinterpret_cast<const u32x2*>(a.addend + rowoff[i] + j * 16) : (u32x2){0u, 0u};
-      }
-      float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        f32x4 c = acc[i][j];
-        if (ADDEND) {
-          c[0] += __uint_as_float(ad[i][0] << 16);
-          c[1] += __uint_as_float(ad[i][0] & 0xFFFF0000u);
-          c[2] += __uint_as_float(ad[i][1] << 16);
-          c[3] += __uint_as_float(ad[i][1] & 0xFFFF0000u);
-        }
-        u32x2 v;
-        v[0] = halo_pack2(c[0], c[1]);
-        v[1] = halo_pack2(c[2], c[3]);
-        if (STATS && valid[i]) {                         // statistics of the ROUNDED outputs
-          const float r0 = __uint_as_float(v[0] << 16), r1 = __uint_as_float(v[0] & 0xFFFF0000u);
-          const float r2 = __uint_as_float(v[1] << 16), r3 = __uint_as_float(v[1] & 0xFFFF0000u);
-          s4[0] += r0; q4[0] += r0 * r0;
-          s4[1] += r1; q4[1] += r1 * r1;
-          s4[2] += r2; q4[2] += r2 * r2;
-          s4[3] += r3; q4[3] += r3 * r3;
-        }
-        if (valid[i]) __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(a.out + rowoff[i] + j * 16));
-      }
-      if (STATS) {
-        // lanes of one fg group (a DPP row of 16) hold the same 4 channels for 16 different pixels; the four wm waves
-        // of a channel half meet in LDS (fp32 per block, fp64 across blocks)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float s = halo_row16_sum(s4[c]), q = halo_row16_sum(q4[c]);
-          if (fr == 0) {
-            const int ch = wn * 64 + j * 16 + fg * 4 + c;
-            __hip_atomic_fetch_add(stats_lds + ch, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(stats_lds + 128 + ch, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int h = 0; h < 2; ++h) {
+          f32x4 c = acc[i][2 * t + h];
+          if (ADDEND) {
+            const unsigned lo = ad[i][t][2 * h], hi = ad[i][t][2 * h + 1];
+            c[0] += __uint_as_float(lo << 16);
+            c[1] += __uint_as_float(lo & 0xFFFF0000u);
+            c[2] += __uint_as_float(hi << 16);
+            c[3] += __uint_as_float(hi & 0xFFFF0000u);
+          }
+          const unsigned w0 = halo_pack2(c[0], c[1]), w1 = halo_pack2(c[2], c[3]);
+          v[2 * h] = w0;
+          v[2 * h + 1] = w1;
+          if (STATS && valid) {                          // statistics of the ROUNDED outputs
+            const float r0 = __uint_as_float(w0 << 16), r1 = __uint_as_float(w0 & 0xFFFF0000u);
+            const float r2 = __uint_as_float(w1 << 16), r3 = __uint_as_float(w1 & 0xFFFF0000u);
+            s8[t][4 * h + 0] += r0; q8[t][4 * h + 0] += r0 * r0;
+            s8[t][4 * h + 1] += r1; q8[t][4 * h + 1] += r1 * r1;
+            s8[t][4 * h + 2] += r2; q8[t][4 * h + 2] += r2 * r2;
+            s8[t][4 * h + 3] += r3; q8[t][4 * h + 3] += r3 * r3;
           }
         }
+        if (valid) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.out + off + t * 32));
       }
+    }
+    if (STATS) {
+      // lanes of one fg group (a DPP row of 16) hold the same 8 channels for 16 different pixels; the four wm waves of
+      // a channel half meet in LDS (fp32 per block, fp64 across blocks)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float sv = halo_row16_sum(s8[t][c]), qv = halo_row16_sum(q8[t][c]);
+          if (fr == 0) {
+            const int ch = wn * 64 + t * 32 + fg * 8 + c;
+            __hip_atomic_fetch_add(stats_lds + ch, sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(stats_lds + 128 + ch, qv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
     }
   }
   }   // MFMA waves

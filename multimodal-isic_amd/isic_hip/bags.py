@@ -7,6 +7,7 @@ import numpy as np
 import torch
 
 _SINGLE_CACHE = {}
+_UNIFORM_CACHE = {}
 
 
 class BagOffsets:
@@ -32,7 +33,15 @@ class BagOffsets:
 
     @classmethod
     def uniform(cls, num_bags, bag_size, device):
-        return cls(np.arange(num_bags + 1, dtype=np.int64) * int(bag_size), device)
+        """Equal-sized bags; cached per (count, size, device): a training loop asks for the same offsets every step
+        and each construction is a host -> device copy."""
+        key = (int(num_bags), int(bag_size), str(device))
+        o = _UNIFORM_CACHE.get(key)
+        if o is None:
+            if len(_UNIFORM_CACHE) > 64:
+                _UNIFORM_CACHE.clear()
+            o = _UNIFORM_CACHE[key] = cls(np.arange(num_bags + 1, dtype=np.int64) * int(bag_size), device)
+        return o
 
     @classmethod
     def from_lengths(cls, lengths, device):

@@ -195,6 +195,9 @@ class GraphStore:
         self.ei = [dev_tensor(r["edge_index"], torch.int64, np.int64)
                    if needs_graph and r.get("edge_index") is not None else None for r in records]
         self.needs_graph = needs_graph
+        # equal-sized graphs (the reference's case): one [G, n, D] tensor, a step's batch is ONE index_select
+        self.y_dev = torch.as_tensor(self.y, device=device)
+        self._xstack = torch.stack(self.x) if self.x and len({tuple(t.shape) for t in self.x}) == 1 else None
         self._single = {}
         self._chunks = {}          # evaluation chunks (sequential index ranges) repeat every epoch: cached whole
         self._stack = None
@@ -260,14 +263,20 @@ class GraphStore:
         key = tuple(int(i) for i in idx)
         if cache and key in self._chunks:
             return self._chunks[key]
-        xs = [self.x[i] for i in idx]
-        lens = [int(t.shape[0]) for t in xs]
-        offs = BagOffsets.from_lengths(lens, self.device)
         if len(idx) == 1:
             i = idx[0]
+            n = int(self.x[i].shape[0])
             if self.needs_graph and i not in self._single:
-                self._single[i] = GraphBatch(self.ei[i], lens[0], mode=self.mode)
-            return xs[0], offs, self._single.get(i)
+                self._single[i] = GraphBatch(self.ei[i], n, mode=self.mode)
+            return self.x[i], BagOffsets.single(n, self.device), self._single.get(i)
+        if self._xstack is not None:
+            n, D = int(self._xstack.shape[1]), int(self._xstack.shape[2])
+            x = self._xstack[torch.as_tensor(key, device=self.device)].reshape(-1, D)
+            offs = BagOffsets.uniform(len(key), n, self.device)
+        else:
+            xs = [self.x[i] for i in idx]
+            x = torch.cat(xs)
+            offs = BagOffsets.from_lengths([int(t.shape[0]) for t in xs], self.device)
         graph = None
         if self.needs_graph:
             if self._stack is not None:
@@ -275,7 +284,7 @@ class GraphStore:
             else:
                 ei = torch.cat([self.ei[i] + int(o) for i, o in zip(idx, offs.host[:-1])], dim=1)
                 graph = GraphBatch(ei, offs.total, mode=self.mode)
-        out = (torch.cat(xs), offs, graph)
+        out = (x, offs, graph)
         if cache:
             self._chunks[key] = out
         return out
