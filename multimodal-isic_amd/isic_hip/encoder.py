@@ -318,6 +318,42 @@ class ResNet18Encoder(nn.Module):
         call("isic_nchw_to_nhwc4_bf16", images, int(images.dtype == _BF16), out, N, C, H, W)
         return out
 
+    def block_forward(self, x, pre, ds):
+        """One BasicBlock: relu(bn2(conv2(relu(bn1(conv1(x))))) + identity), identity = x or
+        bn(conv1x1/2(x)).  ``x`` NHWC bf16.  Returns (out, saved-for-backward)."""
+        idn, cd, std = x, None, None
+        if ds:
+            cd, accd = self._conv_fwd(x, f"{pre}.downsample.0")
+            idn, std = self._bn_fwd(cd, f"{pre}.downsample.1", False, acc=accd)
+        c1, acc1 = self._conv_fwd(x, f"{pre}.conv1")
+        a1, st1 = self._bn_fwd(c1, f"{pre}.bn1", True, acc=acc1)
+        c2, acc2 = self._conv_fwd(a1, f"{pre}.conv2")
+        out, st2 = self._bn_fwd(c2, f"{pre}.bn2", True, residual=idn, acc=acc2)
+        return out, (x, c1, a1, st1, c2, out, st2, cd, std)
+
+    def block_backward(self, g, pre, ds, saved):
+        """Backward of ``block_forward``: ``g`` = d loss / d out (NHWC bf16).  Accumulates the block's parameter
+        gradients into ``param.grad`` and returns (d loss / d x, names of the parameters whose gradients are final)."""
+        x, c1, a1, st1, c2, out, st2, cd, std = saved
+        dc2, dres = self._bn_bwd(g, c2, out, st2, f"{pre}.bn2", True, True)
+        self._conv_wgrad(a1, dc2, f"{pre}.conv2")
+        da1 = self._conv_dgrad(dc2, f"{pre}.conv2", tuple(a1.shape))
+        del dc2
+        dc1, _ = self._bn_bwd(da1, c1, a1, st1, f"{pre}.bn1", True, False, mask_from_x=True)
+        del da1
+        self._conv_wgrad(x, dc1, f"{pre}.conv1")
+        names = [f"{pre}.conv2.weight", f"{pre}.bn2.weight", f"{pre}.bn2.bias", f"{pre}.conv1.weight",
+                 f"{pre}.bn1.weight", f"{pre}.bn1.bias"]
+        if ds:
+            dcd, _ = self._bn_bwd(dres, cd, None, std, f"{pre}.downsample.1", False, False)
+            self._conv_wgrad(x, dcd, f"{pre}.downsample.0")
+            dx2 = self._conv_dgrad(dcd, f"{pre}.downsample.0", tuple(x.shape))
+            dx = self._conv_dgrad(dc1, f"{pre}.conv1", tuple(x.shape), addend=dx2)
+            names += [f"{pre}.downsample.0.weight", f"{pre}.downsample.1.weight", f"{pre}.downsample.1.bias"]
+        else:
+            dx = self._conv_dgrad(dc1, f"{pre}.conv1", tuple(x.shape), addend=dres)   # + identity gradient
+        return dx, names
+
     def run_forward(self, images, save):
         """Returns (features[N,512] fp32, tape).  ``save=False`` drops everything not
         needed (inference)."""
@@ -344,17 +380,9 @@ class ResNet18Encoder(nn.Module):
         tape = {"x0": x0, "stem": (c, st0, am, (N, Ho, Wo, 64)), "blocks": []} if save else None
         x = p
         for pre, ds in self.blocks:
-            idn, cd, std = x, None, None
-            if ds:
-                cd, accd = self._conv_fwd(x, f"{pre}.downsample.0")
-                idn, std = self._bn_fwd(cd, f"{pre}.downsample.1", False, acc=accd)
-            c1, acc1 = self._conv_fwd(x, f"{pre}.conv1")
-            a1, st1 = self._bn_fwd(c1, f"{pre}.bn1", True, acc=acc1)
-            c2, acc2 = self._conv_fwd(a1, f"{pre}.conv2")
-            out, st2 = self._bn_fwd(c2, f"{pre}.bn2", True, residual=idn, acc=acc2)
+            x, saved = self.block_forward(x, pre, ds)
             if save:
-                tape["blocks"].append((x, c1, a1, st1, c2, out, st2, cd, std))
-            x = out
+                tape["blocks"].append(saved)
         N, Hf, Wf, Cf = x.shape
         feat = torch.empty((N, Cf), device=x.device, dtype=torch.float32)
         call("isic_avgpool_fwd_bf16", x, feat, N, Hf * Wf, Cf)
@@ -380,26 +408,7 @@ class ResNet18Encoder(nn.Module):
         g = torch.empty((N, Hf, Wf, Cf), device=dfeat.device, dtype=_BF16)
         call("isic_avgpool_bwd_bf16", dfeat.float().contiguous(), g, N, Hf * Wf, Cf)
         for (pre, ds), saved in zip(reversed(self.blocks), reversed(tape["blocks"])):
-            x, c1, a1, st1, c2, out, st2, cd, std = saved
-            dc2, dres = self._bn_bwd(g, c2, out, st2, f"{pre}.bn2", True, True)
-            self._conv_wgrad(a1, dc2, f"{pre}.conv2")
-            da1 = self._conv_dgrad(dc2, f"{pre}.conv2", tuple(a1.shape))
-            del dc2
-            dc1, _ = self._bn_bwd(da1, c1, a1, st1, f"{pre}.bn1", True, False, mask_from_x=True)
-            del da1
-            self._conv_wgrad(x, dc1, f"{pre}.conv1")
-            names = [f"{pre}.conv2.weight", f"{pre}.bn2.weight", f"{pre}.bn2.bias", f"{pre}.conv1.weight",
-                     f"{pre}.bn1.weight", f"{pre}.bn1.bias"]
-            if ds:
-                dcd, _ = self._bn_bwd(dres, cd, None, std, f"{pre}.downsample.1", False, False)
-                self._conv_wgrad(x, dcd, f"{pre}.downsample.0")
-                dx2 = self._conv_dgrad(dcd, f"{pre}.downsample.0", tuple(x.shape))
-                dx = self._conv_dgrad(dc1, f"{pre}.conv1", tuple(x.shape), addend=dx2)
-                names += [f"{pre}.downsample.0.weight", f"{pre}.downsample.1.weight", f"{pre}.downsample.1.bias"]
-            else:
-                dx = self._conv_dgrad(dc1, f"{pre}.conv1", tuple(x.shape), addend=dres)   # + identity gradient
-            del dc1
-            g = dx
+            g, names = self.block_backward(g, pre, ds, saved)
             self._fire(names)
         c, st0, am, yshape = tape["stem"]
         N, Ho, Wo, _ = yshape

@@ -221,6 +221,61 @@ def main():
             hk.remove()
         np.savez_compressed(os.path.join(OUT, f"graphmil_mlp_{tag}.npz"), **d)
 
+    # ---------------- net_utils.train / validate / test / EarlyStopping (net_utils.py:6-158)
+    # The reference's own loops drive the reference's own MultiModalFusionNet (non-image modalities) on CPU:
+    # two SGD epochs over three dict batches (dropout probabilities set to 0 so that no RNG stream is involved),
+    # then validate / test on a fourth batch, and EarlyStopping over a fixed loss sequence.
+    import contextlib
+    import io
+    nu = load_ref("net_utils.py", "ref_net_utils")
+    R, B = 32, 8
+    net = mdl.MultiModalFusionNet(modality=["radiomics", "clinical", "artifacts"], fusion_level="intermediate",
+                                  fusion_strategy="concat", radiomics_dim=R)
+    shapes = formula.shapes_of(net)
+    net.load_state_dict(formula.formula_state_dict(shapes))
+    for mod in net.modules():
+        if isinstance(mod, nn.Dropout):
+            mod.p = 0.0
+
+    def make_batch(i):
+        return {"image": torch.zeros(B, 1), "radiomics": formula.formula_input(B, R, phase=0.3 + 0.5 * i),
+                "age": formula.ftensor((B,), 0.5, 0.3, 0.1 + i), "sex": (torch.arange(B) + i) % 3,
+                "loc": (torch.arange(B) * 2 + i) % 15, "artifacts": ((torch.arange(B * 6).view(B, 6) + i) % 2),
+                "target": (torch.arange(B) * 3 + i) % 7}
+
+    loader = [make_batch(i) for i in range(3)]
+    held = [make_batch(5)]
+    crit = nn.CrossEntropyLoss()
+    opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9)
+    d = {"names": names_blob(shapes), "B": np.int64(B), "R": np.int64(R)}
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        for ep in range(2):
+            nu.train(net, loader, crit, opt, "cpu", None, ep)
+        d["val_loss"] = np.float64(nu.validate(net, held, crit, "cpu", None, 2))
+        acc, report = nu.test(net, held, "cpu", None)
+    d["test_acc"] = np.float64(acc)
+    d["report"] = np.array(report)
+    d["stdout"] = np.array(buf.getvalue())
+    for k, v in net.state_dict().items():
+        if k.startswith(("image_model", "image_proj")):
+            continue                       # the image branch is not part of this model instance's forward
+        if v.numel() <= 4096:
+            d[f"after.{k}"] = np_(v)
+        else:
+            for kk, vv in sample_stats(v, 512).items():
+                d[f"after.{k}#{kk}"] = vv
+    es = nu.EarlyStopping(patience=3, neptune_run=None)
+    seq = [1.0, 0.8, 0.9, 0.85, 0.7, 0.71, 0.72, 0.73]
+    flags, counters, bests = [], [], []
+    for l in seq:
+        flags.append(bool(es(l, net)))
+        counters.append(es.counter)
+        bests.append(es.best_loss)
+    d["es_losses"], d["es_flags"], d["es_counters"], d["es_best"] = (np.array(seq), np.array(flags), np.array(counters),
+                                                                      np.array(bests))
+    np.savez_compressed(os.path.join(OUT, "net_utils_loops.npz"), **d)
+
     # ---------------- radiomics_mlp / AttentionFusion / fusion branches (model.py:6-227)
     for R in (32, 128):
         for strat in ("concat", "weighted", "attention"):

@@ -1,0 +1,111 @@
+"""Data-parallel evidence on ONE MI355X (an 8-GPU node is not available to the build): the gradient
+exchange is driven from a REAL backward of the flagship model, and sharding a step's bags over ranks
+is shown to give the single-process gradients ("sum of shard grads == single-rank batched
+grads").  The two-rank collective itself is covered on CPU (tests/test_ddp_cpu.py, gloo)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_gradsync_buckets_follow_a_real_backward():
+    """`GradSync.mark_ready(lo)` promises "every gradient at flat offset >= lo is final".  With the
+    encoder's `grad_ready_hook` installed on a real MultiModalMILNet: (i) the hook fires with
+    non-increasing offsets and the launched slices tile [0, numel) exactly once, tail first; (ii) at every
+    `mark_ready(lo)` a snapshot of grad[lo:] (taken on the stream the hook runs on) equals the FINAL
+    grad[lo:] after backward -- in particular autograd has finished every head gradient before the
+    encoder's backward starts, which the overlap relies on."""
+    from isic_hip import ddp, optim
+    from model import MultiModalMILNet
+    torch.manual_seed(0)
+    net = MultiModalMILNet(hidden_dim=32, att_dim=16, dropout=0.0, radiomics_dim=16, num_classes=7).to(DEV)
+    net.train()
+    opt = optim.AdamW(net.parameters(), lr=1e-3)
+    flat = opt.flat
+    sync = ddp.GradSync(flat.grad, world_size=1, bucket_bytes=4 << 20)      # 11.2 M parameters -> ~11 buckets
+    ddp.attach(net.encoder, flat, sync)
+    marks, snaps = [], []
+    orig = sync.mark_ready
+
+    def spy(lo):
+        lo = max(0, min(int(lo), flat.numel))
+        marks.append(lo)
+        snaps.append((lo, flat.grad[lo:].clone()))
+        orig(lo)
+    sync.mark_ready = spy
+    B, K, S = 4, 3, 64
+    g = torch.Generator(device=DEV).manual_seed(1)
+    img = torch.randn(B, K, 3, S, S, device=DEV, generator=g)
+    rad = torch.randn(B, 16, device=DEV, generator=g)
+    y = torch.arange(B, device=DEV) % 7
+    opt.zero_grad()
+    sync.reset()
+    net.loss(net(img, rad), y).backward()
+    launched = sync.finish()
+    torch.cuda.synchronize()
+    assert len(marks) == 9 and marks == sorted(marks, reverse=True) and marks[-1] == 0      # 8 residual blocks + stem
+    assert launched == sorted(launched, reverse=True)                                       # tail of the buffer first
+    cover = sorted(launched)
+    assert cover[0][0] == 0 and cover[-1][1] == flat.numel and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+    assert all(hi - lo >= (4 << 20) // 4 for lo, hi in launched[:-1]) and len(launched) >= 3
+    for lo, snap in snaps:
+        assert torch.equal(snap, flat.grad[lo:]), f"gradients at offsets >= {lo} changed after they were marked final"
+    assert float(flat.grad.abs().sum()) > 0 and bool(torch.isfinite(flat.grad).all())
+
+
+@pytest.mark.parametrize("kind", ["teacher", "graphmil"])
+def test_shard_gradients_sum_to_batched_gradients(kind):
+    """No BatchNorm in the MIL head / GraphMIL: a step over B bags == the sum of the steps over its two rank
+    shards with the loss scaled as the train loops do (local mean * local / global count, train.py), to 1e-5
+    of the gradient scale.  (The encoder's BatchNorm uses per-rank statistics: DESIGN.md 5.)"""
+    import build_graphs as bg
+    from dataset import synthetic_latent_bags
+    from gnn_models import GraphMIL
+    from isic_hip import ddp, ops, train as T
+    from isic_hip.bags import BagOffsets
+    from utils_g_mil import AttentionMIL_teacher
+    torch.manual_seed(2)
+    n, N, D = 10, 24, 32
+    bags, labels = synthetic_latent_bags(n, N, D, classes=7, shift=0.7, seed=4)
+    if kind == "teacher":
+        model = AttentionMIL_teacher(D, 16, 8, dropout=0.0, num_classes=7).to(DEV)
+        store = T.BagStore(bags, torch.device(DEV))
+
+        def loss_of(idx, scale):
+            x, offs = store.batch(idx)
+            y = torch.as_tensor(labels[idx], device=DEV)
+            return ops.cross_entropy(model(x, offs)["bag_logits"], y) * scale
+    else:
+        model = GraphMIL(D, "gcn", 16, 2, 0.0, att_dim=8, att_heads=4, pool_dropout=0.0, classifier_dim=12,
+                         classifier_light=True, num_classes=7).to(DEV)
+        recs = [{"x": b, "edge_index": bg._knn_edge_index(torch.from_numpy(b), 3).numpy(), "y": int(y)}
+                for b, y in zip(bags, labels)]
+        store = T.GraphStore(recs, torch.device(DEV), True, mode=model.graph_mode)
+
+        def loss_of(idx, scale):
+            x, offs, g = store.batch(idx)
+            probs, _ = model(x, offsets=offs, graph=g)
+            return ops.cross_entropy_from_probs(probs, torch.as_tensor(store.y[idx], device=DEV)) * scale
+    model.train()
+    glob = [7, 1, 4, 9, 0, 3, 8]                                   # one step's bags, odd count: shards of 4 and 3
+
+    def grads(parts):
+        for p in model.parameters():
+            p.grad = None
+        for idx, scale in parts:
+            loss_of(idx, scale).backward()
+        return {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    full = grads([(glob, 1.0)])
+    world = 2
+    parts = []
+    for r in range(world):
+        lo, hi = ddp.shard_range(len(glob), r, world)
+        mine = glob[lo:hi]
+        parts.append((mine, len(mine) * world / len(glob)))         # the train loops' scaling; all-reduce SUM, then / world
+    shard = grads(parts)
+    for k in full:
+        a, b = shard[k] / world, full[k]
+        tol = 1e-5 * float(b.abs().max()) + 1e-8
+        assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()), tol)

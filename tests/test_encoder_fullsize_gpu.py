@@ -1,0 +1,175 @@
+"""Encoder parity where round 1 was loose: (a) every BasicBlock's backward, teacher-forced -- the block is fed an
+exact input and upstream gradient and compared with torch autograd of the same fp32 block (<= 2 % per tensor),
+so a systematic error in one block cannot hide behind the chaos of 17 stacked bf16 layers; (b) BASELINE.json
+configs[1] AT ITS REAL SIZE (1024 and 2048 images of 3x224x224 through the whole encoder, forward and backward):
+fused BatchNorm statistics == statistics of the written tensor for every layer, sampled output pixels of every
+convolution vs an fp32 recomputation from the layer's own input, finite gradients, run-to-run equality of the
+deterministic kernels."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def _rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+# (block prefix, Cin, planes, stride, input H = W, images): every block of ResNet-18, the three stride-2 /
+# downsample blocks included; >= 256 samples per channel behind every BatchNorm
+BLOCKS = [("layer1.0", 64, 64, 1, 16, 4), ("layer1.1", 64, 64, 1, 12, 6), ("layer2.0", 64, 128, 2, 16, 8),
+          ("layer2.1", 128, 128, 1, 10, 6), ("layer3.0", 128, 256, 2, 12, 12), ("layer3.1", 256, 256, 1, 7, 8),
+          ("layer4.0", 256, 512, 2, 8, 24), ("layer4.1", 512, 512, 1, 7, 8)]
+
+
+@pytest.mark.parametrize("blk", BLOCKS, ids=[b[0] for b in BLOCKS])
+def test_block_backward_teacher_forced(blk):
+    """HIP BasicBlock forward + backward (`ResNet18Encoder.block_forward / block_backward`) vs torch autograd of
+    the fp32 block on the SAME bf16-exact input, weights and upstream gradient.  The HIP path rounds c1, a1, c2
+    and the output to bf16 (2^-9 relative each), torch does not: <= 2 % per tensor (norm-wise), input gradient
+    and every parameter gradient."""
+    from isic_hip.encoder import ResNet18Encoder
+    pre, cin, planes, stride, H, N = blk
+    ds = stride != 1 or cin != planes
+    torch.manual_seed(hash(pre) % 1000)
+    enc = ResNet18Encoder().to(DEV)
+    enc.train()
+    g = torch.Generator().manual_seed(7)
+    names = [f"{pre}.conv1.weight", f"{pre}.bn1.weight", f"{pre}.bn1.bias", f"{pre}.conv2.weight", f"{pre}.bn2.weight",
+             f"{pre}.bn2.bias"] + ([f"{pre}.downsample.0.weight", f"{pre}.downsample.1.weight",
+                                    f"{pre}.downsample.1.bias"] if ds else [])
+    ref = {}
+    with torch.no_grad():
+        for k in names:
+            p = enc._get(k)
+            if p.dim() == 4:
+                v = (torch.randn(p.shape, generator=g) * float(np.sqrt(2.0 / (p.shape[0] * p.shape[2] * p.shape[3]))))
+                v = v.bfloat16().float()                             # the kernels see bf16 weights: make them exact
+            elif k.endswith("weight"):
+                v = 1.0 + 0.2 * torch.randn(p.shape, generator=g)
+            else:
+                v = 0.1 * torch.randn(p.shape, generator=g)
+            p.copy_(v.to(DEV).contiguous(memory_format=torch.channels_last) if p.dim() == 4 else v.to(DEV))
+            ref[k] = v.clone().requires_grad_(True)
+    x = torch.relu(torch.randn(N, cin, H, H, generator=g)).bfloat16().float()      # a post-ReLU activation
+    Ho = (H + 2 - 3) // stride + 1
+    gout = torch.randn(N, planes, Ho, Ho, generator=g).bfloat16().float()
+    # ---- torch fp32 reference
+    xr = x.clone().requires_grad_(True)
+
+    def bn(t, k):
+        return F.batch_norm(t, None, None, ref[f"{pre}.{k}.weight"], ref[f"{pre}.{k}.bias"], True, 0.1, 1e-5)
+    c1 = F.conv2d(xr, ref[f"{pre}.conv1.weight"], None, stride, 1)
+    a1 = torch.relu(bn(c1, "bn1"))
+    c2 = F.conv2d(a1, ref[f"{pre}.conv2.weight"], None, 1, 1)
+    idn = xr
+    if ds:
+        idn = F.batch_norm(F.conv2d(xr, ref[f"{pre}.downsample.0.weight"], None, stride, 0), None, None,
+                           ref[f"{pre}.downsample.1.weight"], ref[f"{pre}.downsample.1.bias"], True, 0.1, 1e-5)
+    out_ref = torch.relu(bn(c2, "bn2") + idn)
+    out_ref.backward(gout)
+    # ---- HIP block
+    enc.prepare_weights()
+    enc._arena_reset(torch.device(DEV))
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV, BF)
+    out, saved = enc.block_forward(xd, pre, ds)
+    assert _rel(out.float().cpu().permute(0, 3, 1, 2), out_ref.detach()) < 0.01
+    for k in names:
+        enc._get(k).grad = None
+    enc._arena_reset(torch.device(DEV))
+    dx, done = enc.block_backward(gout.permute(0, 2, 3, 1).contiguous().to(DEV, BF), pre, ds, saved)
+    torch.cuda.synchronize()
+    assert set(done) == set(names)
+    errs = {"dx": _rel(dx.float().cpu().permute(0, 3, 1, 2), xr.grad)}
+    for k in names:
+        errs[k] = _rel(enc._get(k).grad.cpu(), ref[k].grad)
+    bad = {k: round(v, 4) for k, v in errs.items() if v > 0.02}
+    assert not bad, f"{pre}: relative gradient errors above 2 %: {bad} (all: { {k: round(v, 4) for k, v in errs.items()} })"
+
+
+def _conv_samples(x, wf, out, spec, n_samples, gen):
+    """fp32 recomputation of `n_samples` random output pixels (all output channels) of one convolution from the
+    layer's own bf16 input and bf16 weights; returns max |diff| / (2^-7 |ref| + small)."""
+    N, H, W, C = x.shape
+    _, Ho, Wo, Co = out.shape
+    k, s, p = spec.k, spec.stride, spec.pad
+    n = torch.randint(0, N, (n_samples,), generator=gen, device=DEV)
+    ho = torch.randint(0, Ho, (n_samples,), generator=gen, device=DEV)
+    wo = torch.randint(0, Wo, (n_samples,), generator=gen, device=DEV)
+    w = wf.view(Co, k, k, C).float()
+    acc = torch.zeros(n_samples, Co, device=DEV, dtype=torch.float32)
+    for kh in range(k):
+        for kw in range(k):
+            hi, wi = ho * s + kh - p, wo * s + kw - p
+            ok = (hi >= 0) & (hi < H) & (wi >= 0) & (wi < W)
+            px = x[n, hi.clamp(0, H - 1), wi.clamp(0, W - 1)].float() * ok.view(-1, 1).float()      # [S, C]
+            acc += px @ w[:, kh, kw, :].t()
+    got = out[n, ho, wo].float()
+    tol = (2.0 ** -7) * acc.abs() + 2e-3 * float(acc.abs().max()) * 2 ** -4
+    return float(((got - acc).abs() / tol).max())
+
+
+@pytest.mark.parametrize("images", [1024, 2048])
+def test_configs1_full_size_forward_backward(images):
+    """16 and 32 bags x 64 patches of 3x224x224 (bench.py's per-GPU step) through the whole ResNet-18."""
+    from isic_hip.encoder import ResNet18Encoder
+    torch.manual_seed(5)
+    enc = ResNet18Encoder().to(DEV)
+    enc.train()
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(images, 3, 224, 224, device=DEV, generator=gen).to(BF)
+    feat, tape = enc.run_forward(x, save=True)
+    assert feat.shape == (images, 512) and bool(torch.isfinite(feat).all())
+    # ---- every convolution: sampled outputs vs fp32 recomputation; every BatchNorm: fused statistics == statistics
+    #      of the tensor that was written (mean / rstd are what the backward passes and the apply kernels use)
+    worst = {}
+
+    def check_bn(c, st, name):
+        mean, rstd = st[0], st[1]
+        cf = c.float().view(-1, c.shape[-1])
+        m = cf.mean(0, dtype=torch.float64)
+        v = (cf.double() - m).pow(2).mean(0)
+        assert float((mean.double() - m).abs().max()) <= 1e-5 * float(m.abs().max()) + 1e-6, name
+        r = (v + 1e-5).rsqrt()
+        assert float(((rstd.double() - r).abs() / r).max()) <= 1e-4, name
+
+    c, st0, am, _ = tape["stem"]
+    x0 = tape["x0"]                                      # NHWC4 bf16
+    ws, _ = enc._weights("conv1", False)
+    check_bn(c, st0, "bn1")
+    for (pre, ds), saved in zip(enc.blocks, tape["blocks"]):
+        xin, c1, a1, st1, c2, out, st2, cd, std = saved
+        for nm, inp, o in ((f"{pre}.conv1", xin, c1), (f"{pre}.conv2", a1, c2)) + (((f"{pre}.downsample.0", xin, cd),) if ds else ()):
+            wf, _ = enc._weights(nm, False)
+            worst[nm] = _conv_samples(inp, wf, o, enc.specs[nm], 256, gen)
+        check_bn(c1, st1, f"{pre}.bn1")
+        check_bn(c2, st2, f"{pre}.bn2")
+        if ds:
+            check_bn(cd, std, f"{pre}.downsample.1")
+        assert bool(torch.isfinite(out.float()).all()), pre
+    bad = {k: round(v, 3) for k, v in worst.items() if v > 1.0}
+    assert not bad, f"sampled conv outputs beyond one bf16 rounding of the fp32 recomputation: {bad}"
+    # ---- backward: finite gradients everywhere, and run-to-run equality where the kernels are deterministic
+    dfeat = torch.randn(images, 512, device=DEV, generator=gen) / images
+
+    def grads():
+        for p in enc.parameters():
+            p.grad = None
+        enc.run_backward(tape, dfeat)
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().clone() for k, p in enc.named_parameters()}
+    g1 = grads()
+    g2 = grads()
+    for k, v in g1.items():
+        assert bool(torch.isfinite(v).all()) and float(v.abs().max()) > 0, k
+    for k in g1:
+        a, b = g1[k], g2[k]
+        if k.startswith(("layer1.", "layer2.1", "layer2.0.conv2")) and k.endswith(("conv1.weight", "conv2.weight")):
+            assert torch.equal(a, b), f"{k}: the all-taps weight gradient must be deterministic"
+        else:
+            assert _rel(a, b) < 1e-4, k               # fp32 / fp64 atomics: last-bit differences only

@@ -137,3 +137,69 @@ def test_early_stopping_counts_down():
     assert es(1.0, m) is False and es.counter == 2
     assert es(1.5, m) is False and es.counter == 1
     assert es(1.2, m) is True and es.get_best_model_state() is not None
+
+
+def test_early_stopping_matches_reference_golden():
+    """`net_utils.EarlyStopping` (reference `net_utils.py:130-158`): counter counts DOWN from patience, returns True at
+    zero, keeps the best state -- against the reference's own object over a fixed loss sequence (golden)."""
+    import net_utils as nu
+    g = np.load(os.path.join(ROOT, "tests", "golden", "net_utils_loops.npz"), allow_pickle=False)
+    model = torch.nn.Linear(2, 2)
+    es = nu.EarlyStopping(patience=3, neptune_run=None)
+    best_w = None
+    for l, flag, counter, best in zip(g["es_losses"], g["es_flags"], g["es_counters"], g["es_best"]):
+        with torch.no_grad():
+            model.weight.add_(1.0)
+        if l < es.best_loss:
+            best_w = model.weight.detach().clone()
+        assert bool(es(float(l), model)) == bool(flag)
+        assert es.counter == int(counter) and es.best_loss == float(best)
+    assert torch.equal(es.get_best_model_state()["weight"], best_w)
+
+
+def test_derm_dataset_dict_contract(tmp_path):
+    """`DermDataset.__getitem__` (reference `dataset.py:21-56`): the ten keys in the reference's order, dtypes and
+    shapes, the 'no_mask' path, defaults for absent clinical columns, radiomics = zeros(102) unless a frame is given,
+    and default collation into the dict batch `net_utils` consumes (`net_utils.py:11-19`)."""
+    import pandas as pd
+    from PIL import Image
+    from dataset import ARTIFACT_COLS, DermDataset
+    rng = np.random.RandomState(0)
+    paths = []
+    for i, (h, w) in enumerate([(40, 60), (50, 50)]):
+        ip = str(tmp_path / f"img{i}.png")
+        Image.fromarray(rng.randint(0, 255, (h, w, 3), dtype=np.uint8)).save(ip)
+        paths.append(ip)
+    mask = np.zeros((40, 60), dtype=np.uint8)
+    mask[10:20, 40:55] = 255                                   # lesion off-centre: the square crop follows it
+    mp = str(tmp_path / "mask0.png")
+    Image.fromarray(mask).save(mp)
+    df = pd.DataFrame({"image_path": paths, "segmentation_path": [mp, "no_mask"], "dx": [3, 5],
+                       "age_normalized": [0.25, 0.75], "sex_encoded": [1, 2], "loc_encoded": [7, 14],
+                       **{c: [i % 2, (i + 1) % 2] for i, c in enumerate(ARTIFACT_COLS)}})
+    ds = DermDataset(df, None)
+    assert len(ds) == 2
+    it = ds[0]
+    assert list(it.keys()) == ["image", "mask", "radiomics", "age", "sex", "loc", "artifacts", "target", "image_path",
+                               "segmentation_path"]
+    assert it["image"].shape == (3, 40, 40) and it["image"].dtype == torch.float32 and float(it["image"].max()) <= 1.0
+    assert it["mask"].shape == (1, 40, 40) and float(it["mask"].sum()) == 10 * 15       # the whole lesion is inside the crop
+    assert it["radiomics"].shape == (102,) and it["radiomics"].dtype == torch.float32 and not it["radiomics"].any()
+    assert it["age"].dtype == torch.float32 and abs(float(it["age"]) - 0.25) < 1e-7
+    assert it["sex"].dtype == torch.long and int(it["sex"]) == 1 and int(it["loc"]) == 7
+    assert it["artifacts"].dtype == torch.long and it["artifacts"].tolist() == [0, 1, 0, 1, 0, 1]
+    assert it["target"].dtype == torch.long and int(it["target"]) == 3
+    assert it["image_path"] == paths[0] and it["segmentation_path"] == mp
+    it1 = ds[1]
+    assert it1["image"].shape == (3, 50, 50) and not it1["mask"].any()                 # 'no_mask' -> empty mask
+    # absent clinical / artifact columns fall back to the reference's defaults
+    bare = DermDataset(df[["image_path", "segmentation_path", "dx"]], None)[1]
+    assert float(bare["age"]) == 0.0 and int(bare["sex"]) == 0 and int(bare["loc"]) == 0 and not bare["artifacts"].any()
+    # a radiomics frame (the north-star path) replaces the zero stub
+    rad = pd.DataFrame(rng.randn(2, 12).astype(np.float32))
+    assert torch.equal(DermDataset(df, rad)[1]["radiomics"], torch.as_tensor(rad.iloc[1].values))
+    # default collation -> the dict batch net_utils moves to the device key by key
+    ds2 = DermDataset(pd.concat([df.iloc[[1]]] * 3, ignore_index=True), None)
+    batch = next(iter(torch.utils.data.DataLoader(ds2, batch_size=3)))
+    assert batch["image"].shape == (3, 3, 50, 50) and batch["radiomics"].shape == (3, 102)
+    assert batch["artifacts"].shape == (3, 6) and batch["target"].tolist() == [5, 5, 5] and len(batch["image_path"]) == 3
