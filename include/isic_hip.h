@@ -153,6 +153,20 @@ int isic_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 int isic_knn_graph(const float* x, const int64_t* offsets, int G, int D, int k, int max_nodes, int64_t total_nodes,
                    int64_t* nn_idx, float* nn_dist, float* workspace_sqnorm, void* stream);
 
+/* Edge-wise heterophily measures of a patch graph (04_measure_heterophily.py:107-169), per directed edge
+ * e = (src[e] -> dst[e]) of a batch of graphs (global node ids; every graph has nodes_per_graph nodes laid out on a
+ * grid_w-wide lattice, 04:124-125):
+ *   h_kl[e]        = sum_c p[src,c] * log((p[src,c] + eps) / (p[dst,c] + eps))      (:164)
+ *   h_dirichlet[e] = 0.5 * || x[src] - x[dst] ||^2                                  (:165)
+ *   h_spatial[e]   = Euclidean lattice distance of the two patches                  (:166)
+ *   same_class[e]  = 1.0 iff dominant_class[src] == dominant_class[dst]             (:130)
+ * x[T,D], probs[T,C] fp32, dominant_class[T] int32, src/dst[E] int64.  Self loops are NOT dropped (the reference
+ * strips them first, :117-118): the caller filters on src != dst, which keeps the reference's edge order. */
+int isic_edge_heterophily_f32(const float* x, const float* probs, const int32_t* dominant_class, const int64_t* src,
+                              const int64_t* dst, int64_t num_edges, int D, int C, int grid_w, int nodes_per_graph,
+                              float eps, float* h_kl, float* h_dirichlet, float* h_spatial, float* same_class,
+                              void* stream);
+
 /* CSR-by-destination with GCN symmetric normalisation (PyG GCNConv.gcn_norm as
  * called at 05_train_gnns.py:82,184-185): existing self loops are dropped, one
  * self loop (weight 1, or the dropped loop's weight) is added per node,

@@ -221,6 +221,36 @@ def main():
             hk.remove()
         np.savez_compressed(os.path.join(OUT, f"graphmil_mlp_{tag}.npz"), **d)
 
+    # ---------------- heterophily measures (04_measure_heterophily.py:107-169), the reference's own numpy code
+    h04 = load_ref("04_measure_heterophily.py", "ref_heterophily", tolerate=(FileNotFoundError, OSError))
+    Nn, Dd, Cc = 196, 48, 7
+    emb = formula.formula_input(Nn, Dd, phase=0.4).numpy()
+    logits = formula.formula_input(Nn, Cc, phase=1.1) * 3.0
+    pp = torch.softmax(logits, dim=1).numpy()
+    row = {"patch_embeddings": emb, "patch_probs": pp, "dominant_class": pp.argmax(axis=1).astype(np.int32),
+           "grid4_edge_index": g03._grid_edge_index(False).numpy(), "grid8_edge_index": g03._grid_edge_index(True).numpy(),
+           "knn_edge_indices": {k: g03._knn_edge_index(torch.from_numpy(emb), k).numpy() for k in (3, 8)},
+           "random_edge_indices": {r: g03._random_edge_index(Nn, r, 42 + r).numpy() for r in (2,)}}
+
+    class _Row:                      # the reference reads attributes of an itertuples() row
+        def __init__(self, d):
+            self.__dict__.update(d)
+    # one variant with self loops and a duplicated edge mixed in: the reference strips loops before averaging
+    loops = np.stack([np.arange(0, Nn, 7), np.arange(0, Nn, 7)])
+    row["edge_index"] = np.concatenate([row["knn_edge_indices"][3][:, :300], loops, row["knn_edge_indices"][3][:, :5]], axis=1)
+    d = {"N": np.int64(Nn), "D": np.int64(Dd), "C": np.int64(Cc), "edge_index": row["edge_index"]}
+    for variant in (None, "grid4", "grid8", "knn3", "knn8", "random2"):
+        em = h04.compute_edge_heterophily(_Row(row), graph_variant=variant)
+        tag = variant or "raw"
+        for k in ("H_kl", "H_dirichlet", "H_spatial", "lambda_2", "H_compat_matrix"):
+            d[f"{tag}.{k}"] = np.asarray(em[k], dtype=np.float64)
+        d[f"{tag}.H_adj"] = np.float64(em["H_adj"])
+        sm = h04._summarize_image(em, {})
+        for k in ("num_edges", "H_kl_mean", "H_kl_std", "H_kl_median", "H_dirichlet_mean", "H_spatial_median", "H_adj_mean",
+                  "lambda_2_mean"):
+            d[f"{tag}.sum.{k}"] = np.float64(sm[k])
+    np.savez_compressed(os.path.join(OUT, "heterophily.npz"), **d)
+
     # ---------------- net_utils.train / validate / test / EarlyStopping (net_utils.py:6-158)
     # The reference's own loops drive the reference's own MultiModalFusionNet (non-image modalities) on CPU:
     # two SGD epochs over three dict batches (dropout probabilities set to 0 so that no RNG stream is involved),

@@ -242,3 +242,45 @@ def test_gat_attention_dropout_matches_oracle():
     pr, _ = m(x.to(DEV), ei.to(DEV))
     o = gnn.graphmil_forward(p, cfg, x, ei, drop={"seed": 77, "stream_base": 2 * 1024})
     assert_close(pr, o["probs"], rtol=5e-5, atol=2e-6, what="gat dropout probs")
+
+
+def test_heterophily_measures_vs_reference_golden_and_oracle():
+    """`measure_heterophily.compute_edge_heterophily` (HIP edge kernel + device class bookkeeping + batched
+    eigensolve) vs the reference's own numpy function on a 196-node image (tests/golden/heterophily.npz: raw edge
+    list with self loops and duplicates, both grids, k-NN, random), and the batched form vs the numpy oracle on a
+    batch of random images with different graphs."""
+    import build_graphs as bg
+    import measure_heterophily as mh
+    from oracle import formula, heterophily as oh
+    g = load_golden("heterophily.npz")
+    N, D, C = int(g["N"]), int(g["D"]), int(g["C"])
+    emb = formula.formula_input(N, D, phase=0.4).numpy()
+    pp = torch.softmax(formula.formula_input(N, C, phase=1.1) * 3.0, dim=1).numpy()
+    row = {"patch_embeddings": emb, "patch_probs": pp, "dominant_class": pp.argmax(axis=1).astype(np.int32),
+           "edge_index": g["edge_index"], "grid4_edge_index": bg._grid_edge_index(False).numpy(),
+           "grid8_edge_index": bg._grid_edge_index(True).numpy(),
+           "knn_edge_indices": {k: bg._knn_edge_index(torch.from_numpy(emb), k).cpu().numpy() for k in (3, 8)},
+           "random_edge_indices": {2: bg._random_edge_index(N, 2, 44).numpy()}}
+    for variant in (None, "grid4", "grid8", "knn3", "knn8", "random2"):
+        em = mh.compute_edge_heterophily(row, graph_variant=variant)
+        tag = variant or "raw"
+        for k in ("H_kl", "H_dirichlet", "H_spatial", "H_compat_matrix"):
+            np.testing.assert_allclose(em[k], g[f"{tag}.{k}"], rtol=2e-5, atol=2e-6, err_msg=f"{tag}.{k}")
+        assert abs(em["H_adj"] - float(g[f"{tag}.H_adj"])) < 1e-9, tag
+        np.testing.assert_allclose(em["lambda_2"], g[f"{tag}.lambda_2"], rtol=1e-5, atol=1e-6, err_msg=f"{tag}.lambda_2")
+        sm = mh.summarize_image(em, {"image_id": "x"})
+        assert sm["num_edges"] == int(g[f"{tag}.sum.num_edges"]) and sm["image_id"] == "x"
+        for k in ("H_kl_mean", "H_kl_std", "H_kl_median", "H_dirichlet_mean", "H_spatial_median", "H_adj_mean", "lambda_2_mean"):
+            assert abs(sm[k] - float(g[f"{tag}.sum.{k}"])) <= 2e-5 * abs(float(g[f"{tag}.sum.{k}"])) + 2e-6, (tag, k)
+    # batched: 5 images, different k per image, vs the numpy oracle image by image
+    rs = np.random.RandomState(3)
+    embs = [rs.randn(N, 24).astype(np.float32) for _ in range(5)]
+    pps = [torch.softmax(torch.from_numpy(rs.randn(N, C).astype(np.float32)) * 2, dim=1).numpy() for _ in range(5)]
+    doms = [p.argmax(axis=1).astype(np.int32) for p in pps]
+    eis = [bg._knn_edge_index(torch.from_numpy(e), k).cpu().numpy() for e, k in zip(embs, (1, 2, 4, 8, 16))]
+    got = mh.compute_edge_heterophily_batch(embs, pps, doms, eis)
+    for i in range(5):
+        ref = oh.edge_heterophily(embs[i], pps[i], doms[i], eis[i])
+        for k in ("H_kl", "H_dirichlet", "H_spatial", "H_compat_matrix", "lambda_2"):
+            np.testing.assert_allclose(got[i][k], ref[k], rtol=2e-5, atol=2e-6, err_msg=f"image {i} {k}")
+        assert abs(got[i]["H_adj"] - ref["H_adj"]) < 1e-9

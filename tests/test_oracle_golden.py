@@ -127,3 +127,25 @@ def test_metrics():
     assert abs(metrics.balanced_accuracy(g["y"], g["scores"].argmax(axis=1)) - float(g["bacc"])) < 1e-12
     with pytest.raises(ValueError):
         metrics.roc_auc_ovr_macro(np.zeros(8, dtype=int), np.full((8, 7), 1 / 7))
+
+
+def test_heterophily_oracle_matches_reference_golden():
+    """oracle/heterophily.py vs the reference's own `compute_edge_heterophily` (04_measure_heterophily.py:107-169) on
+    a 196-node image: raw edge list with self loops and duplicated edges, both grids, k-NN and random graphs."""
+    from oracle import formula, heterophily
+    from oracle import graphs as ograph
+    g = load_golden("heterophily.npz")
+    N, D, C = int(g["N"]), int(g["D"]), int(g["C"])
+    emb = formula.formula_input(N, D, phase=0.4).numpy()
+    pp = torch.softmax(formula.formula_input(N, C, phase=1.1) * 3.0, dim=1).numpy()
+    dom = pp.argmax(axis=1).astype(np.int32)
+    variants = {"raw": g["edge_index"], "grid4": ograph.grid_edge_index(14, False), "grid8": ograph.grid_edge_index(14, True),
+                "knn3": ograph.knn_edge_index(torch.from_numpy(emb), 3), "knn8": ograph.knn_edge_index(torch.from_numpy(emb), 8),
+                "random2": ograph.random_edge_index(N, 2, 44)}
+    for tag, ei in variants.items():
+        em = heterophily.edge_heterophily(emb, pp, dom, np.asarray(ei))
+        for k in ("H_kl", "H_dirichlet", "H_spatial", "H_compat_matrix"):
+            np.testing.assert_allclose(em[k], g[f"{tag}.{k}"], rtol=1e-5, atol=1e-6, err_msg=f"{tag}.{k}")
+        assert abs(em["H_adj"] - float(g[f"{tag}.H_adj"])) < 1e-9, tag
+        # the reference's adjacency is float32 (04:150): a zero eigenvalue comes out as ~1e-8 noise there
+        np.testing.assert_allclose(em["lambda_2"], g[f"{tag}.lambda_2"], rtol=1e-5, atol=1e-6, err_msg=f"{tag}.lambda_2")

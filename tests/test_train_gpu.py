@@ -177,6 +177,14 @@ def test_pipeline_01_02_03_05_synthetic(tmp_path):
             "random_edge_indices"} <= set(gdf.columns)
     assert gdf["knn_edge_indices"].iloc[0][8].shape == (2, 196 * 8) and gdf["grid4_edge_index"].iloc[0].shape == (2, 728)
     assert int(gdf["knn_edge_indices"].iloc[3][8].max()) < 196
+    out4 = run(os.path.join(PKG, "04_measure_heterophily.py"), "--graph-outputs-root", "graph_outputs", "--patch-stats-root",
+               "patch_stats", "--out-csv", "heterophily.csv")
+    import pandas as pd
+    hdf = pd.read_csv(tmp_path / "heterophily.csv")
+    assert {"graph_variant", "graph_type", "graph_param", "num_edges", "H_kl_mean", "H_dirichlet_median", "H_adj_mean",
+            "lambda_2_mean"} <= set(hdf.columns) and "22 graph variants" in out4
+    assert np.isfinite(hdf[["H_kl_mean", "H_dirichlet_mean", "H_spatial_mean", "H_adj_mean", "lambda_2_mean"]].values).all()
+    assert (hdf[hdf.graph_variant == "grid4"].H_spatial_mean == 1.0).all()       # lattice neighbours are 1 apart
     run(os.path.join(PKG, "05_train_gnns.py"), "--root", str(tmp_path), "--gnn", "gcn", "mlp", "--variants", "knn4",
         "grid4", "--folds", "0", "--epochs", "1", "--hidden-dim", "32", "--graphs-per-step", "4")
     import pandas as pd
@@ -186,3 +194,63 @@ def test_pipeline_01_02_03_05_synthetic(tmp_path):
     out2 = run(os.path.join(PKG, "05_train_gnns.py"), "--root", str(tmp_path), "--gnn", "gcn", "--variants", "knn4",
                "--folds", "0", "--epochs", "1", "--hidden-dim", "32")
     assert "Skipping completed experiment" in out2      # resume
+
+
+def test_on_device_teacher_to_graph_pipeline_matches_pickle_path():
+    """teacher outputs -> dominant class -> all-k k-NN -> GNN training without leaving HBM
+    (`pipeline.py`) == the stage-by-stage path through the reference's three frame schemas (`isic_hip.train.
+    collect_teacher_outputs` = 01:69-87, 02's arg-max, `build_graphs.build_graph_records` = 03:95-149): identical
+    edge lists for every k, identical dominant classes, probabilities to 1e-6, identical exported frames; and the
+    05 fold loop trained from the resident records reproduces the loop trained from the pickled records."""
+    import build_graphs as bg
+    import pandas as pd
+    import pipeline
+    from dataset import synthetic_latent_bags
+    from gnn_models import GraphMIL
+    from isic_hip import train as T
+    from utils_g_mil import AttentionMIL_teacher
+    dev = torch.device(DEV)
+    bags, labels = synthetic_latent_bags(24, 196, 32, classes=7, shift=0.8, seed=3)
+    ids = [f"img_{i:03d}" for i in range(len(bags))]
+    torch.manual_seed(0)
+    teacher = AttentionMIL_teacher(32, 16, 8, dropout=0.5, num_classes=7).to(dev)
+    # ---- pickle path
+    tdf = T.collect_teacher_outputs(teacher, bags, labels, ids, dev)
+    pdf = pd.DataFrame({"image_id": tdf["image_id"], "label": tdf["label"], "patch_embeddings": tdf["patch_embeddings"],
+                        "patch_probs": tdf["patch_probs"], "dominant_class": [np.argmax(p, axis=1) for p in tdf["patch_probs"]]})
+    recs = bg.build_graph_records(pdf, "m", 0, "train", list(bg.DEFAULT_K_VALUES), [2], 42)
+    # ---- resident path
+    out = pipeline.collect_teacher_outputs_device(teacher, bags, labels, ids, dev)
+    assert out.x.is_cuda and out.patch_probs.is_cuda and out.knn.is_cuda and out.dominant_class.is_cuda
+    for i in (0, 7, 23):
+        assert np.abs(out.patch_probs[i].cpu().numpy() - tdf["patch_probs"].iloc[i]).max() < 1e-6
+        assert np.abs(out.attention[i].cpu().numpy() - tdf["attention"].iloc[i]).max() < 1e-6
+        assert np.array_equal(out.dominant_class[i].cpu().numpy(), pdf["dominant_class"].iloc[i])
+    for k in bg.DEFAULT_K_VALUES:
+        e = out.knn_edge_index(k).cpu().numpy()
+        for i in (0, 5, 23):
+            assert np.array_equal(e[i], recs[i]["knn_edge_indices"][int(k)]), (k, i)
+    gf = out.graph_frame("m", 0, "train", r_values=[2])
+    assert list(gf.columns) == list(pd.DataFrame(recs).columns)
+    for i in (0, 11):
+        assert np.array_equal(gf["random_edge_indices"].iloc[i][2], recs[i]["random_edge_indices"][2])
+        assert np.array_equal(gf["grid8_edge_index"].iloc[i], recs[i]["grid8_edge_index"])
+    assert list(out.teacher_frame().columns) == list(tdf.columns) and list(out.patch_stats_frame().columns) == list(pdf.columns)
+    # ---- the GNN loop straight from the resident records == the loop from the pickled records
+    def fit(records_of):
+        torch.manual_seed(1)
+        m = GraphMIL(32, "gcn", 16, 2, 0.0, att_dim=8, att_heads=4, pool_dropout=0.0, classifier_dim=12,
+                     classifier_light=True, num_classes=7).to(dev)
+        tr, va = records_of(slice(0, 16)), records_of(slice(16, 24))
+        vm, _, _ = T.train_gnn_fold(m, tr, va, va[:3], lr=2e-3, epochs=2, graphs_per_step=4, num_classes=7, device=dev,
+                                    rng=np.random.RandomState(5))
+        return vm, {k: v.detach().clone() for k, v in m.state_dict().items()}
+    res_recs = out.graph_records("knn4")
+    assert res_recs[0]["x"].is_cuda and res_recs[0]["edge_index"].is_cuda
+    pick = [{"x": pdf["patch_embeddings"].iloc[i], "edge_index": recs[i]["knn_edge_indices"][4], "y": int(pdf["label"].iloc[i])}
+            for i in range(24)]
+    vm_a, sd_a = fit(lambda s: res_recs[s])
+    vm_b, sd_b = fit(lambda s: pick[s])
+    assert abs(vm_a["loss"] - vm_b["loss"]) < 1e-5 and vm_a["bacc"] == vm_b["bacc"]
+    for k in sd_a:
+        assert torch.allclose(sd_a[k], sd_b[k], atol=1e-6), k
