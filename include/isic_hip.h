@@ -153,6 +153,41 @@ int isic_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 int isic_knn_graph(const float* x, const int64_t* offsets, int G, int D, int k, int max_nodes, int64_t total_nodes,
                    int64_t* nn_idx, float* nn_dist, float* workspace_sqnorm, void* stream);
 
+/* Edge-attention message passing for the remaining PyG layers GraphMIL can select (05_train_gnns.py:94-106), on the
+ * destination-major CSR (rowptr/col) and its transpose (rowptr_t/col_t/perm_t) of isic_gcn_csr_build.  Tensors are
+ * [N, H, F] fp32 row-major; alpha/de are [nnz, H].
+ *   mode 0 (GATv2Conv, 05:99-101):    logit = sum_f att[h,f] * leaky_relu(ks[src] + qd[dst]); values v == ks (= lin_l(x));
+ *                                     qd = lin_r(x); CSR built in mode 'gcn' (self loops re-added).
+ *   mode 1 (TransformerConv, 05:94-98): logit = scale * <qd[dst], ks[src]>, ks = key, qd = query, v = value; CSR built in
+ *                                     mode 'sum' (edges as given); a node without incoming edges gets out = bias.
+ * alpha = softmax of the logits over the edges INTO each destination, per head; dropout (Philox word p*H+h) on alpha;
+ * out[dst,h,:] = sum alpha * v[src,h,:] (+ bias[H*F]).  fwd writes the pre-dropout alpha.
+ * bwd: de[nnz,H] = d logit (workspace and output), dqd = d loss / d qd, dks = d loss / d ks (mode 0: including the
+ * value path, v == ks), dv = d loss / d v (mode 1 only), datt[H,F] += d loss / d att (mode 0 only; zero it first;
+ * needs F % 64 == 0 and H*F <= 512). */
+int isic_edge_attn_fwd(int mode, const float* ks, const float* qd, const float* v, const float* att, const int32_t* rowptr,
+                       const int32_t* col, const float* bias, float* out, float* alpha, int64_t N, int H, int F,
+                       float negative_slope, float scale, uint32_t drop_threshold, float drop_scale, uint64_t seed,
+                       uint64_t stream_id, void* stream);
+int isic_edge_attn_bwd(int mode, const float* dout, const float* ks, const float* qd, const float* v, const float* att,
+                       const float* alpha, const int32_t* rowptr, const int32_t* col, const int32_t* rowptr_t,
+                       const int32_t* col_t, const int32_t* perm_t, float* de, float* dqd, float* dks, float* dv, float* datt,
+                       int64_t N, int H, int F, float negative_slope, float scale, uint32_t drop_threshold, float drop_scale,
+                       uint64_t seed, uint64_t stream_id, void* stream);
+/* FAConv (05:102-105, restated from the published layer: the reference's call passes the wrong arguments):
+ * out[dst,:] = sum_e tanh(al[src] + ar[dst]) * val[e] * x[src,:] + eps * x0[dst,:] with al = <x, att_l>, ar = <x, att_r>
+ * (isic_gat_scores with H = 1) and val = the GCN normalisation of a 'gcn'-mode CSR; dropout on the tanh scores (Philox
+ * word p).  coef[nnz] receives the pre-dropout tanh score.  bwd: de[nnz], dar[N], dal[N] are outputs / workspace,
+ * dx[N,F] = d loss / d x including the att_l / att_r paths (d att_l = dal^T x, d att_r = dar^T x and d x0 = eps * dout
+ * are formed by the caller). */
+int isic_fa_fwd(const float* x, const float* x0, const float* al, const float* ar, const int32_t* rowptr, const int32_t* col,
+                const float* val, float* out, float* coef, int64_t N, int F, float eps, uint32_t drop_threshold,
+                float drop_scale, uint64_t seed, uint64_t stream_id, void* stream);
+int isic_fa_bwd(const float* dout, const float* x, const float* coef, const float* att_l, const float* att_r,
+                const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* rowptr_t, const int32_t* col_t,
+                const float* val_t, const int32_t* perm_t, float* de, float* dar, float* dal, float* dx, int64_t N, int F,
+                uint32_t drop_threshold, float drop_scale, uint64_t seed, uint64_t stream_id, void* stream);
+
 /* Edge-wise heterophily measures of a patch graph (04_measure_heterophily.py:107-169), per directed edge
  * e = (src[e] -> dst[e]) of a batch of graphs (global node ids; every graph has nodes_per_graph nodes laid out on a
  * grid_w-wide lattice, 04:124-125):
