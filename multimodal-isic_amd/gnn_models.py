@@ -10,9 +10,13 @@ Graph models: ``mlp`` (pure dense, pinned by the reference), ``gcn``, ``gcnii``,
 ``graphsage`` (mean aggregation + L2 normalisation), ``gin`` (sum aggregation) and ``gat``
 (per-destination edge softmax, the reference's tuned graph model) -- PyG ``GCNConv`` /
 ``GCN2Conv`` / ``SAGEConv`` / ``GINConv`` / ``GATConv`` semantics restated (``torch_geometric``
-is absent and unpinned in the reference, see oracle/gnn.py).  ``gatv2`` and ``fagcn`` are
-mis-sized / mis-called in the reference itself and, with ``transformer``, are not
-built: they raise ``NotImplementedError``.
+is absent and unpinned in the reference, see oracle/gnn.py), plus ``gatv2`` (GATv2Conv),
+``transformer`` (TransformerConv(beta=True)) and ``fagcn`` (FAConv) on the edge-attention kernels of
+``edge_attn.hip``.  Two of those cannot run as the reference writes them: its ``gatv2``
+branch does not widen ``out_dim`` by the head count although ``concat=True`` (`05_train_gnns.py:99-101`),
+so the following LayerNorm rejects the layer's output, and ``fagcn`` is called as
+``layer(h, edge_index, edge_weight)`` (`:184-185`) whereas the layer takes ``(x, x_0, edge_index)``.
+Here ``gatv2`` widens like ``gat`` and ``fagcn`` receives ``x_0`` = the projected input (as ``gcnii``).
 
 Beyond the reference: ``forward`` also takes a batch of graphs (``offsets`` + global node ids,
 or a prebuilt ``GraphBatch``) and returns ``probs[G, C]``.
@@ -26,12 +30,16 @@ import torch.nn as nn
 
 from isic_hip import ops
 from isic_hip.bags import BagOffsets, as_offsets
-from isic_hip.graph import GraphBatch, gat_conv, l2_normalize, spmm
+from isic_hip.graph import (GraphBatch, fa_conv, gat_conv, gatv2_conv, l2_normalize, spmm,
+                            transformer_attention)
 from utils_g_mil import _DropoutClock
 
 GNN_TYPES = ("mlp", "gcn", "gat", "gatv2", "gin", "graphsage", "transformer", "fagcn", "gcnii")
-_BUILT = ("mlp", "gcn", "gcnii", "graphsage", "gin", "gat")
-_GRAPH_MODE = {"gcn": "gcn", "gcnii": "gcn", "graphsage": "mean", "gin": "sum", "gat": "gcn"}
+_BUILT = GNN_TYPES
+# CSR the layer aggregates over: 'gcn' = self loops re-added (+ symmetric normalisation where the layer uses it),
+# 'sum' / 'mean' = the edges as given (TransformerConv adds no self loops)
+_GRAPH_MODE = {"gcn": "gcn", "gcnii": "gcn", "graphsage": "mean", "gin": "sum", "gat": "gcn", "gatv2": "gcn",
+               "transformer": "sum", "fagcn": "gcn"}
 
 
 class _GCNConvParams(nn.Module):
@@ -70,6 +78,47 @@ class _GATConvParams(nn.Module):
         self.heads, self.out_dim = heads, out_dim
 
 
+class _GATv2ConvParams(nn.Module):
+    """PyG ``GATv2Conv(in, F, heads=H, concat=True)``: ``att`` [1,H,F] (Glorot), ``bias`` [H*F] (zeros),
+    ``lin_l`` / ``lin_r`` Linear(in, H*F) with bias (Glorot weights, zero biases)."""
+
+    def __init__(self, in_dim, out_dim, heads):
+        super().__init__()
+        self.att = nn.Parameter(torch.empty(1, heads, out_dim))
+        self.bias = nn.Parameter(torch.zeros(heads * out_dim))
+        self.lin_l = nn.Linear(in_dim, heads * out_dim, bias=True)
+        self.lin_r = nn.Linear(in_dim, heads * out_dim, bias=True)
+        for t in (self.att, self.lin_l.weight, self.lin_r.weight):
+            nn.init.xavier_uniform_(t)
+        nn.init.zeros_(self.lin_l.bias)
+        nn.init.zeros_(self.lin_r.bias)
+        self.heads, self.out_dim = heads, out_dim
+
+
+class _TransformerConvParams(nn.Module):
+    """PyG ``TransformerConv(in, F, heads=H, concat=True, beta=True)``: ``lin_key`` / ``lin_query`` / ``lin_value`` /
+    ``lin_skip`` Linear(in, H*F) with bias, ``lin_beta`` Linear(3*H*F, 1, bias=False)."""
+
+    def __init__(self, in_dim, out_dim, heads):
+        super().__init__()
+        self.lin_key = nn.Linear(in_dim, heads * out_dim)
+        self.lin_query = nn.Linear(in_dim, heads * out_dim)
+        self.lin_value = nn.Linear(in_dim, heads * out_dim)
+        self.lin_skip = nn.Linear(in_dim, heads * out_dim)
+        self.lin_beta = nn.Linear(3 * heads * out_dim, 1, bias=False)
+        self.heads, self.out_dim = heads, out_dim
+
+
+class _FAConvParams(nn.Module):
+    """PyG ``FAConv(channels, eps=0.1)``: ``att_l`` / ``att_r`` Linear(channels, 1, bias=False)."""
+
+    def __init__(self, channels, eps=0.1):
+        super().__init__()
+        self.att_l = nn.Linear(channels, 1, bias=False)
+        self.att_r = nn.Linear(channels, 1, bias=False)
+        self.eps = float(eps)
+
+
 class _SAGEConvParams(nn.Module):
     """PyG ``SAGEConv(aggr='mean', normalize=True)``: ``lin_l`` (neighbour mean, with bias) and
     ``lin_r`` (root, no bias)."""
@@ -97,9 +146,6 @@ class GraphMIL(nn.Module):
         self.gnn_type = gnn_type.lower()
         if self.gnn_type not in GNN_TYPES:
             raise ValueError(f"Unsupported gnn_type: {self.gnn_type}")           # 05:113-114
-        if self.gnn_type not in _BUILT:
-            raise NotImplementedError(f"gnn_type '{self.gnn_type}' is not built on the HIP path yet "
-                                      f"(available: {', '.join(_BUILT)})")
         self.use_residual, self.use_layer_norm = use_residual, use_layer_norm
         self.classifier_light, self.gnn_heads, self.gnn_concat = classifier_light, gnn_heads, gnn_concat
         if (use_residual or self.gnn_type in {"fagcn", "gcnii"}) and input_dim != gnn_hidden:   # 05:65-68
@@ -122,6 +168,20 @@ class GraphMIL(nn.Module):
                     raise NotImplementedError("GATConv(concat=False) is not built on the HIP path")
                 layer = _GATConvParams(in_dim, out_dim, gnn_heads, gnn_concat)
                 out_dim *= gnn_heads
+            elif self.gnn_type == 'gatv2':                                       # 05:99-101 (+ the widening of :86)
+                if not gnn_concat:
+                    raise NotImplementedError("GATv2Conv(concat=False) is not built on the HIP path")
+                layer = _GATv2ConvParams(in_dim, out_dim, gnn_heads)
+                out_dim *= gnn_heads
+            elif self.gnn_type == 'transformer':                                 # 05:94-98
+                if not gnn_concat:
+                    raise NotImplementedError("TransformerConv(concat=False) is not built on the HIP path")
+                layer = _TransformerConvParams(in_dim, out_dim, gnn_heads)
+                out_dim *= gnn_heads
+            elif self.gnn_type == 'fagcn':                                       # 05:102-105
+                if in_dim != out_dim:
+                    raise ValueError("FAGCN requires a constant hidden dimension")
+                layer = _FAConvParams(out_dim, eps=0.1)
             elif self.gnn_type == 'graphsage':                                   # 05:87-88
                 layer = _SAGEConvParams(in_dim, out_dim)
             elif self.gnn_type == 'gin':                                         # 05:89-93
@@ -191,6 +251,21 @@ class GraphMIL(nn.Module):
             elif self.gnn_type == 'gat':           # edge softmax over the CSR rows; attention dropout = site 32 + i
                 h = gat_conv(ops.linear(h, layer.lin.weight, None), layer.att_src, layer.att_dst, layer.bias, g,
                              layer.heads, 0.2, clk.spec(p_drop, 32 + i, tr))
+            elif self.gnn_type == 'gatv2':         # edge softmax of att . leaky_relu(x_l[src] + x_r[dst]); dropout site 32 + i
+                h = gatv2_conv(ops.linear(h, layer.lin_l.weight, layer.lin_l.bias),
+                               ops.linear(h, layer.lin_r.weight, layer.lin_r.bias), layer.att, layer.bias, g, layer.heads,
+                               0.2, clk.spec(p_drop, 32 + i, tr))
+            elif self.gnn_type == 'transformer':   # scaled dot-product edge softmax + gated skip (beta)
+                agg = transformer_attention(ops.linear(h, layer.lin_query.weight, layer.lin_query.bias),
+                                            ops.linear(h, layer.lin_key.weight, layer.lin_key.bias),
+                                            ops.linear(h, layer.lin_value.weight, layer.lin_value.bias), g, layer.heads,
+                                            clk.spec(p_drop, 32 + i, tr))
+                xr = ops.linear(h, layer.lin_skip.weight, layer.lin_skip.bias)
+                # the scalar gate per node is index plumbing on [N, 3*H*F] -> [N, 1]: one fp32 GEMM + torch elementwise
+                beta = torch.sigmoid(ops.linear(torch.cat([agg, xr, agg - xr], dim=1), layer.lin_beta.weight, None))
+                h = beta * xr + (1.0 - beta) * agg
+            elif self.gnn_type == 'fagcn':         # tanh-gated, GCN-normalised aggregation + eps * x0
+                h = fa_conv(h, x0, layer.att_l.weight, layer.att_r.weight, g, layer.eps, clk.spec(p_drop, 32 + i, tr))
             elif self.gnn_type == 'graphsage':     # lin_l(mean_j x_j) + lin_r(x_i), then row L2 normalisation
                 h = l2_normalize(ops.linear(spmm(h, g), layer.lin_l.weight, layer.lin_l.bias)
                                  + ops.linear(h, layer.lin_r.weight, None))

@@ -193,3 +193,102 @@ class GatFn(torch.autograd.Function):
 
 def gat_conv(xp, att_src, att_dst, bias, graph, heads, negative_slope=0.2, drop=None):
     return GatFn.apply(xp, att_src, att_dst, bias, graph, heads, negative_slope, drop)
+
+
+class EdgeAttnFn(torch.autograd.Function):
+    """Edge-softmax attention aggregation of ``isic_edge_attn_fwd/bwd``.
+    mode 0 (GATv2Conv): ks = x_l (also the values), qd = x_r, att[H,F]; 'gcn'-mode GraphBatch (self loops re-added).
+    mode 1 (TransformerConv): ks = key, qd = query, v = value, scale = 1/sqrt(F); 'sum'-mode GraphBatch."""
+
+    @staticmethod
+    def forward(ctx, mode, ks, qd, v, att, bias, graph, heads, slope, scale, drop):
+        from .ops import NO_DROP
+        _chk(ks, qd, v, att, bias)
+        ks, qd = _f32c(ks), _f32c(qd)
+        v = ks if mode == 0 else _f32c(v)
+        N, HF = ks.shape
+        F_ = HF // heads
+        a = _f32c(att).reshape(heads, F_) if att is not None else None
+        drop = drop or NO_DROP
+        alpha = torch.empty((graph.col.numel(), heads), device=ks.device, dtype=torch.float32)
+        out = torch.empty_like(ks)
+        call("isic_edge_attn_fwd", int(mode), ks, qd, v, a, graph.rowptr, graph.col, _f32c(bias) if bias is not None else None,
+             out, alpha, N, heads, F_, float(slope), float(scale), drop.threshold, drop.scale, drop.seed, drop.stream)
+        ctx.graph, ctx.cfg = graph, (int(mode), N, heads, F_, float(slope), float(scale), drop, bias is not None,
+                                     att.shape if att is not None else None)
+        ctx.save_for_backward(ks, qd, v, a, alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ks, qd, v, a, alpha = ctx.saved_tensors
+        mode, N, H, F_, slope, scale, drop, has_bias, att_shape = ctx.cfg
+        g = ctx.graph
+        dout = _f32c(dout)
+        dev = ks.device
+        de = torch.empty_like(alpha)
+        dqd, dks = torch.empty_like(qd), torch.empty_like(ks)
+        dv = torch.empty_like(v) if mode == 1 else None
+        datt = torch.zeros((H, F_), device=dev, dtype=torch.float32) if mode == 0 else None
+        call("isic_edge_attn_bwd", mode, dout, ks, qd, v, a, alpha, g.rowptr, g.col, g.rowptr_t, g.col_t, g.perm_t, de, dqd,
+             dks, dv, datt, N, H, F_, slope, scale, drop.threshold, drop.scale, drop.seed, drop.stream)
+        db = colsum(dout) if has_bias else None
+        return (None, dks, dqd, dv, datt.reshape(att_shape) if datt is not None else None, db, None, None, None, None, None)
+
+
+def gatv2_conv(xl, xr, att, bias, graph, heads, negative_slope=0.2, drop=None):
+    return EdgeAttnFn.apply(0, xl, xr, None, att, bias, graph, heads, negative_slope, 1.0, drop)
+
+
+def transformer_attention(q, k, v, graph, heads, drop=None):
+    F_ = q.shape[1] // heads
+    return EdgeAttnFn.apply(1, k, q, v, None, None, graph, heads, 0.0, 1.0 / (F_ ** 0.5), drop)
+
+
+class FaFn(torch.autograd.Function):
+    """FAConv propagation on a 'gcn'-mode GraphBatch: out = sum tanh(<x,att_l>[src] + <x,att_r>[dst]) * w * x[src] +
+    eps * x0 (``isic_fa_fwd/bwd``; the two scalar scores per node come from ``isic_gat_scores`` with one head)."""
+
+    @staticmethod
+    def forward(ctx, x, x0, att_l, att_r, graph, eps, drop):
+        from .ops import NO_DROP
+        _chk(x, x0, att_l, att_r)
+        x, x0 = _f32c(x), _f32c(x0)
+        N, F_ = x.shape
+        al_w, ar_w = _f32c(att_l).reshape(1, F_), _f32c(att_r).reshape(1, F_)
+        drop = drop or NO_DROP
+        dev = x.device
+        al = torch.empty((N, 1), device=dev, dtype=torch.float32)
+        ar = torch.empty((N, 1), device=dev, dtype=torch.float32)
+        call("isic_gat_scores", x, al_w, ar_w, al, ar, N, 1, F_)
+        coef = torch.empty(graph.col.numel(), device=dev, dtype=torch.float32)
+        out = torch.empty_like(x)
+        call("isic_fa_fwd", x, x0, al, ar, graph.rowptr, graph.col, graph.val, out, coef, N, F_, float(eps), drop.threshold,
+             drop.scale, drop.seed, drop.stream)
+        ctx.graph, ctx.cfg = graph, (N, F_, float(eps), drop, att_l.shape, att_r.shape)
+        ctx.save_for_backward(x, al_w, ar_w, coef)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .ops import gemm
+        x, al_w, ar_w, coef = ctx.saved_tensors
+        N, F_, eps, drop, shp_l, shp_r = ctx.cfg
+        g = ctx.graph
+        dout = _f32c(dout)
+        dev = x.device
+        de = torch.empty_like(coef)
+        dar = torch.empty((N, 1), device=dev, dtype=torch.float32)
+        dal = torch.empty((N, 1), device=dev, dtype=torch.float32)
+        dx = torch.empty_like(x)
+        call("isic_fa_bwd", dout, x, coef, al_w, ar_w, g.rowptr, g.col, g.val, g.rowptr_t, g.col_t, g.val_t, g.perm_t, de, dar,
+             dal, dx, N, F_, drop.threshold, drop.scale, drop.seed, drop.stream)
+        d_l = torch.empty((1, F_), device=dev, dtype=torch.float32)
+        d_r = torch.empty((1, F_), device=dev, dtype=torch.float32)
+        gemm(dal, x, trans_a=True, out=d_l)              # d att_l = dal^T x
+        gemm(dar, x, trans_a=True, out=d_r)
+        return dx, dout * eps, d_l.reshape(shp_l), d_r.reshape(shp_r), None, None, None
+
+
+def fa_conv(x, x0, att_l, att_r, graph, eps=0.1, drop=None):
+    return FaFn.apply(x, x0, att_l, att_r, graph, eps, drop)

@@ -16,6 +16,19 @@ PARITY UNPINNED for the message-passing layers: the reference calls
             self loops re-added, dropout on alpha, concat heads, + bias
   SAGEConv: lin_l(mean_j x_j) + lin_r(x_i), L2-normalised rows (aggr='mean', normalize=True)
   GINConv : nn((1 + eps) x_i + sum_j x_j), eps trainable, init 0
+  GATv2Conv: x_l = lin_l(x), x_r = lin_r(x) (both with bias), viewed [N,H,F]; self loops removed then one added per
+            node; e = sum_f att[h,f] * leaky_relu(x_l[src] + x_r[dst], 0.2); alpha = softmax over the edges into dst;
+            dropout on alpha; out[dst] = sum alpha x_l[src]; concat heads; + bias.  (The reference does NOT widen
+            out_dim by the head count for gatv2 although concat=True, `05_train_gnns.py:99-101` vs `:83-86`, so its
+            LayerNorm(out_dim) cannot accept the layer's output for heads > 1; restated WITH the widening, like gat.)
+  TransformerConv(beta=True): q = lin_query(x), k = lin_key(x), v = lin_value(x) viewed [N,H,F]; alpha = softmax over
+            the edges into dst of <q[dst], k[src]> / sqrt(F) (NO self loops added); dropout on alpha;
+            out = concat_h sum alpha v[src]; x_r = lin_skip(x); b = sigmoid(lin_beta([out, x_r, out - x_r]));
+            out = b * x_r + (1 - b) * out.
+  FAConv  : (x, x_0, edge_index) -- the reference passes (h, edge_index, edge_weight), `05_train_gnns.py:184-185`,
+            which is not the layer's signature; restated from the published layer with x_0 = the projected input
+            (as GCN2Conv): w = gcn_norm(edge_index) with self loops; a = tanh(att_l(x)[src] + att_r(x)[dst]); dropout
+            on a; out[dst] = sum a * w * x[src] + eps * x_0[dst] (eps = 0.1).
 The ``mlp`` graph model is pure torch in the reference and IS pinned by
 ``tests/golden/graphmil_mlp_*.npz``.
 """
@@ -124,6 +137,74 @@ def gin_conv(x, edge_index, eps, w0, b0, w2, b2):
     return F.linear(F.relu(F.linear(z, w0, b0)), w2, b2)
 
 
+def _dst_major_slots(src, dst):
+    """CSR slot of every edge in the destination-major order of the product (stable sort by destination)."""
+    order = torch.argsort(dst, stable=True)
+    slot = torch.empty_like(order)
+    slot[order] = torch.arange(order.numel())
+    return slot
+
+
+def _edge_softmax(e, dst, n):
+    heads = e.shape[1]
+    emax = torch.full((n, heads), -float("inf"), dtype=e.dtype).scatter_reduce(0, dst.view(-1, 1).expand(-1, heads), e, "amax")
+    ex = torch.exp(e - emax[dst])
+    den = torch.zeros(n, heads, dtype=e.dtype).index_add_(0, dst, ex)
+    return ex / den[dst]
+
+
+def _alpha_dropout(alpha, slot, drop):
+    if drop is None or drop["p"] <= 0.0:
+        return alpha
+    from . import philox
+    heads = alpha.shape[1] if alpha.dim() > 1 else 1
+    keep = torch.from_numpy(philox.dropout_keep(alpha.shape[0] * heads, drop["p"], drop["seed"], drop["stream"]))
+    keep = keep.view(-1, heads) if alpha.dim() > 1 else keep.view(-1)
+    scale = torch.tensor(float(philox.dropout_scale(drop["p"])), dtype=alpha.dtype)
+    return torch.where(keep[slot], alpha * scale, torch.zeros((), dtype=alpha.dtype))
+
+
+def gatv2_conv(x, edge_index, lin_l_w, lin_l_b, lin_r_w, lin_r_b, att, bias, heads, negative_slope=0.2, drop=None):
+    """PyG GATv2Conv(in, F, heads, concat=True, share_weights=False) -- see the module docstring."""
+    n = x.size(0)
+    xl = F.linear(x, lin_l_w, lin_l_b).view(n, heads, -1)
+    xr = F.linear(x, lin_r_w, lin_r_b).view(n, heads, -1)
+    keep = edge_index[0] != edge_index[1]
+    loops = torch.arange(n, dtype=edge_index.dtype)
+    src = torch.cat([edge_index[0][keep], loops])
+    dst = torch.cat([edge_index[1][keep], loops])
+    e = (F.leaky_relu(xl[src] + xr[dst], negative_slope) * att.view(1, heads, -1)).sum(-1)      # [E', H]
+    alpha = _alpha_dropout(_edge_softmax(e, dst, n), _dst_major_slots(src, dst), drop)
+    out = torch.zeros(n, heads, xl.shape[-1], dtype=x.dtype).index_add_(0, dst, alpha.unsqueeze(-1) * xl[src])
+    return out.reshape(n, -1) + bias
+
+
+def transformer_conv(x, edge_index, p, prefix, heads, drop=None):
+    """PyG TransformerConv(in, F, heads, concat=True, beta=True, root_weight=True) -- see the module docstring."""
+    n = x.size(0)
+    lin = lambda name: F.linear(x, p[f"{prefix}.{name}.weight"], p[f"{prefix}.{name}.bias"])
+    q, k, v = (lin(nm).view(n, heads, -1) for nm in ("lin_query", "lin_key", "lin_value"))
+    src, dst = edge_index[0], edge_index[1]
+    e = (q[dst] * k[src]).sum(-1) / math.sqrt(q.shape[-1])
+    alpha = _alpha_dropout(_edge_softmax(e, dst, n), _dst_major_slots(src, dst), drop) if src.numel() else e
+    out = torch.zeros(n, heads, v.shape[-1], dtype=x.dtype).index_add_(0, dst, alpha.unsqueeze(-1) * v[src]).reshape(n, -1)
+    xr = lin("lin_skip")
+    beta = torch.sigmoid(F.linear(torch.cat([out, xr, out - xr], dim=-1), p[f"{prefix}.lin_beta.weight"]))
+    return beta * xr + (1.0 - beta) * out
+
+
+def fa_conv(x, x0, edge_index, att_l_w, att_r_w, eps=0.1, drop=None):
+    """PyG FAConv(channels, eps=0.1, normalize=True, add_self_loops=True) -- see the module docstring."""
+    n = x.size(0)
+    ei, w = gcn_norm(edge_index, None, n, x.dtype)
+    src, dst = ei[0], ei[1]
+    al = F.linear(x, att_l_w).view(-1)
+    ar = F.linear(x, att_r_w).view(-1)
+    a = _alpha_dropout(torch.tanh(al[src] + ar[dst]), _dst_major_slots(src, dst), drop)
+    out = torch.zeros_like(x).index_add_(0, dst, (a * w).unsqueeze(-1) * x[src])
+    return out + eps * x0
+
+
 DEFAULT_CFG = dict(  # the 05 call site, `05_train_gnns.py:310-326`
     gnn_type="gcn", gnn_hidden=128, gnn_layers=2, gnn_dropout=0.5, gnn_heads=4,
     gnn_concat=True, gcnii_alpha=0.1, gcnii_theta=0.5, att_dim=128, att_heads=4,
@@ -171,10 +252,30 @@ def graphmil_shapes(input_dim, cfg):
         elif t == "mlp":
             s[f"gnn_layers.{i}.0.weight"] = (F_, in_dim)
             s[f"gnn_layers.{i}.0.bias"] = (F_,)
+        elif t == "gatv2":       # PyG GATv2Conv: att, bias, lin_l.{weight,bias}, lin_r.{weight,bias}
+            hh = c["gnn_heads"]
+            s[f"gnn_layers.{i}.att"] = (1, hh, F_)
+            s[f"gnn_layers.{i}.bias"] = (hh * F_,)
+            for nm in ("lin_l", "lin_r"):
+                s[f"gnn_layers.{i}.{nm}.weight"] = (hh * F_, in_dim)
+                s[f"gnn_layers.{i}.{nm}.bias"] = (hh * F_,)
+            in_dim = hh * F_
+            continue
+        elif t == "transformer":  # PyG TransformerConv(beta=True)
+            hh = c["gnn_heads"]
+            for nm in ("lin_key", "lin_query", "lin_value", "lin_skip"):
+                s[f"gnn_layers.{i}.{nm}.weight"] = (hh * F_, in_dim)
+                s[f"gnn_layers.{i}.{nm}.bias"] = (hh * F_,)
+            s[f"gnn_layers.{i}.lin_beta.weight"] = (1, 3 * hh * F_)
+            in_dim = hh * F_
+            continue
+        elif t == "fagcn":        # PyG FAConv: att_l.weight, att_r.weight
+            s[f"gnn_layers.{i}.att_l.weight"] = (1, F_)
+            s[f"gnn_layers.{i}.att_r.weight"] = (1, F_)
         else:
             raise ValueError(f"Unsupported gnn_type: {t}")
         in_dim = F_
-    Fo = F_ * c["gnn_heads"] if t == "gat" else F_       # GATConv(concat=True) widens the features, 05:86
+    Fo = F_ * c["gnn_heads"] if t in ("gat", "gatv2", "transformer") else F_   # concat=True widens the features, 05:86,98
     if c["use_layer_norm"]:
         for i in range(c["gnn_layers"]):
             s[f"layer_norms.{i}.weight"] = (Fo,)
@@ -230,6 +331,18 @@ def graphmil_forward(p, cfg, x, edge_index=None, edge_weight=None, drop=None):
         elif t == "gin":
             h = gin_conv(h, edge_index, p[f"gnn_layers.{i}.eps"], p[f"gnn_layers.{i}.nn.0.weight"],
                          p[f"gnn_layers.{i}.nn.0.bias"], p[f"gnn_layers.{i}.nn.2.weight"], p[f"gnn_layers.{i}.nn.2.bias"])
+        elif t in ("gatv2", "transformer", "fagcn"):
+            adrop = None
+            if drop is not None and c["gnn_dropout"] > 0:
+                adrop = {"p": c["gnn_dropout"], "seed": drop["seed"], "stream": drop["stream_base"] + 32 + i}
+            pre = f"gnn_layers.{i}"
+            if t == "gatv2":
+                h = gatv2_conv(h, edge_index, p[f"{pre}.lin_l.weight"], p[f"{pre}.lin_l.bias"], p[f"{pre}.lin_r.weight"],
+                               p[f"{pre}.lin_r.bias"], p[f"{pre}.att"], p[f"{pre}.bias"], c["gnn_heads"], 0.2, adrop)
+            elif t == "transformer":
+                h = transformer_conv(h, edge_index, p, pre, c["gnn_heads"], adrop)
+            else:
+                h = fa_conv(h, x0, edge_index, p[f"{pre}.att_l.weight"], p[f"{pre}.att_r.weight"], 0.1, adrop)
         else:
             raise ValueError(f"Unsupported gnn_type: {t}")
         if c["use_layer_norm"]:

@@ -244,6 +244,59 @@ def test_gat_attention_dropout_matches_oracle():
     assert_close(pr, o["probs"], rtol=5e-5, atol=2e-6, what="gat dropout probs")
 
 
+@pytest.mark.parametrize("gtype,F_,heads", [("gatv2", 64, 4), ("gatv2", 128, 4), ("transformer", 32, 4), ("transformer", 48, 2),
+                                            ("fagcn", 64, 4), ("fagcn", 96, 4)])
+def test_graphmil_edge_attention_models_vs_oracle(gtype, F_, heads):
+    """GATv2Conv / TransformerConv(beta) / FAConv GraphMIL (edge_attn.hip) forward + every gradient vs the published-
+    layer restatements of oracle/gnn.py (PARITY UNPINNED: torch_geometric absent) on a k-NN graph with added self
+    loops, a duplicated edge and -- for the transformer, which adds no self loops -- nodes without incoming edges."""
+    import build_graphs as bg
+    from gnn_models import GraphMIL
+    from isic_hip import ops
+    N, D, L = 150, (F_ if gtype == "fagcn" else 40), 2
+    cfg = dict(gnn_type=gtype, gnn_hidden=F_, gnn_layers=L, gnn_heads=heads, att_dim=16, classifier_dim=24)
+    shapes = gnn.graphmil_shapes(D, cfg)
+    p = formula.formula_state_dict(shapes)
+    x = torch.randn(N, D, generator=torch.Generator().manual_seed(6))
+    ei = bg._knn_edge_index(x, 5).cpu()
+    ei = ei[:, ei[1] % 7 != 3]                                        # some nodes lose every incoming edge
+    ei = torch.cat([ei, torch.tensor([[2, 9, 9], [2, 9, 17]]), ei[:, :4]], dim=1)      # self loops + duplicated edges
+    loss_o, out_o, grads_o = gnn.graphmil_loss_and_grads(p, cfg, x, ei, 2)
+    m = GraphMIL(input_dim=D, gnn_type=gtype, gnn_hidden=F_, gnn_layers=L, gnn_dropout=0.5, gnn_heads=heads, att_dim=16,
+                 att_heads=4, pool_dropout=0.2, classifier_dim=24, classifier_light=True, num_classes=7)
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == list(shapes.items())
+    m.load_state_dict(p)
+    m = m.to(DEV).eval()
+    xd = x.to(DEV).requires_grad_(True)
+    probs, att = m(xd, ei.to(DEV))
+    assert_close(probs, out_o["probs"], rtol=5e-5, atol=2e-6, what="probs")
+    assert_close(att, out_o["att"], rtol=5e-5, atol=2e-6, what="att")
+    assert_close(m.last_node_embeddings, out_o["hs"][-1], rtol=5e-5, atol=5e-6, what="node embeddings")
+    loss = ops.cross_entropy_from_probs(probs.unsqueeze(0), torch.tensor([2], device=DEV))
+    assert_close(loss, loss_o, rtol=5e-5)
+    loss.backward()
+    for k, prm in m.named_parameters():
+        if k.startswith("attention_layers") and k.endswith("2.bias"):
+            continue
+        assert_close(prm.grad, grads_o[k], rtol=5e-4, atol=3e-6, what=k)
+    assert_close(xd.grad, grads_o["x"], rtol=5e-4, atol=3e-6, what="x")
+    # train mode: dropout on the attention coefficients (CSR-slot indexed words) and on the node features
+    m.train()
+    m.set_dropout_state(seed=55, step=1)
+    pr, _ = m(x.to(DEV), ei.to(DEV))
+    o = gnn.graphmil_forward(p, dict(cfg, gnn_dropout=0.5, pool_dropout=0.2), x, ei, drop={"seed": 55, "stream_base": 1024})
+    assert_close(pr, o["probs"], rtol=5e-5, atol=2e-6, what="dropout probs")
+
+
+def test_graphmil_rejects_unknown_type_and_builds_all_reference_types():
+    """`05_train_gnns.py:113-114`: ValueError for an unknown gnn_type; every type the reference lists constructs."""
+    from gnn_models import GNN_TYPES, GraphMIL
+    with pytest.raises(ValueError):
+        GraphMIL(32, "sgc")
+    for t in GNN_TYPES:
+        GraphMIL(64, t, 64, 2)
+
+
 def test_heterophily_measures_vs_reference_golden_and_oracle():
     """`measure_heterophily.compute_edge_heterophily` (HIP edge kernel + device class bookkeeping + batched
     eigensolve) vs the reference's own numpy function on a 196-node image (tests/golden/heterophily.npz: raw edge

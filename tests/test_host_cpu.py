@@ -61,8 +61,9 @@ def test_cpu_tensors_are_rejected_everywhere():
         GraphMIL(8, "mlp", 8, 1, 0.0, att_dim=4, classifier_dim=4, classifier_light=True)(torch.zeros(5, 8))
     with pytest.raises(IsicHipError):
         MultiModalMILNet(hidden_dim=8, att_dim=4, radiomics_dim=4, encoder_layers=((64, 1),))(torch.zeros(2, 2, 3, 32, 32), torch.zeros(2, 4))
-    with pytest.raises(NotImplementedError):
-        GraphMIL(8, "gatv2")
+    with pytest.raises(ValueError):                      # 05:113-114
+        GraphMIL(8, "sgc")
+    GraphMIL(64, "fagcn", 64, 2)                         # every type the reference lists is built
     assert [k for k in GraphMIL(8, "gin", 8, 1).state_dict() if k.startswith("gnn_layers")] == [
         "gnn_layers.0.eps", "gnn_layers.0.nn.0.weight", "gnn_layers.0.nn.0.bias", "gnn_layers.0.nn.2.weight",
         "gnn_layers.0.nn.2.bias"]
