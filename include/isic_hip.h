@@ -153,6 +153,10 @@ int isic_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 int isic_knn_graph(const float* x, const int64_t* offsets, int G, int D, int k, int max_nodes, int64_t total_nodes,
                    int64_t* nn_idx, float* nn_dist, float* workspace_sqnorm, void* stream);
 
+/* Lesion-mask -> patch flags of the latent extraction path (save_latent.py:73-87): mask[B,H,W] fp32,
+ * flags[B, H/patch, W/patch] = 1 iff the patch x patch pixel block holds any value > 0 (H, W multiples of patch). */
+int isic_mask_patch_flags_f32(const float* mask, uint8_t* flags, int64_t B, int H, int W, int patch, void* stream);
+
 /* Edge-attention message passing for the remaining PyG layers GraphMIL can select (05_train_gnns.py:94-106), on the
  * destination-major CSR (rowptr/col) and its transpose (rowptr_t/col_t/perm_t) of isic_gcn_csr_build.  Tensors are
  * [N, H, F] fp32 row-major; alpha/de are [nnz, H].

@@ -75,3 +75,38 @@ int isic_edge_heterophily_f32(const float* x, const float* probs, const int32_t*
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Lesion-mask -> patch flags (save_latent.py:73-87): flags[b, i, j] = 1 iff the P x P pixel block (i, j) of mask b
+// holds any value > 0.  One wave per patch; lanes stride the block's pixels; a ballot reduces.
+namespace {
+
+__global__ __launch_bounds__(256) void mask_patch_flags_kernel(const float* __restrict__ mask, unsigned char* __restrict__ flags,
+                                                               int64_t B, int H, int W, int P) {
+  const int lane = threadIdx.x & 63;
+  const int gh = H / P, gw = W / P;
+  const int64_t total = B * gh * gw;
+  for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < total; w += (int64_t)gridDim.x * 4) {
+    const int64_t b = w / (gh * gw);
+    const int r = (int)(w - b * (gh * gw));
+    const int pi = r / gw, pj = r - pi * gw;
+    const float* base = mask + (b * H + (int64_t)pi * P) * W + (int64_t)pj * P;
+    bool any = false;
+    for (int t = lane; t < P * P; t += 64) any |= base[(int64_t)(t / P) * W + (t % P)] > 0.f;
+    const unsigned long long bal = __ballot(any);
+    if (lane == 0) flags[w] = bal != 0ull ? 1 : 0;
+  }
+}
+
+}  // namespace
+
+extern "C" int isic_mask_patch_flags_f32(const float* mask, uint8_t* flags, int64_t B, int H, int W, int patch, void* stream) {
+  ISIC_CHECK_ARG(B >= 0 && H > 0 && W > 0 && patch > 0 && H % patch == 0 && W % patch == 0);
+  if (B == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(mask && flags);
+  int64_t blocks = (B * (H / patch) * (W / patch) + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(mask_patch_flags_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), mask, flags, B, H, W,
+                     patch);
+  return isic_launch_status();
+}

@@ -393,6 +393,30 @@ class ResNet18Encoder(nn.Module):
                     self._get(name + ".num_batches_tracked").add_(1)
         return feat, tape
 
+    @torch.no_grad()
+    def run_tokens(self, images, stage=3):
+        """Frozen-encoder token grid of the latent extraction path (`save_latent.py:53-60`): the activation after
+        residual stage ``stage`` as ``[N, h*w, C]`` fp32 tokens.  At stage 3 a 224x224 image gives 14x14 = 196 tokens of
+        256 channels, one per 16x16-pixel patch -- the geometry of the reference's ViT latents (`save_latent.py:77`)."""
+        if self.training:
+            raise IsicHipError("run_tokens is an inference path: call eval() first (running BatchNorm statistics)")
+        self.prepare_weights()
+        x0 = self.pack_input(images)
+        self._arena_reset(x0.device)
+        N, H, W, _ = x0.shape
+        Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        ws, _ = self._weights("conv1", False)
+        c = _empty((N, Ho, Wo, 64), x0)
+        call("isic_conv_stem_fwd_bf16", x0, ws, c, N, H, W, Ho, Wo)
+        st0 = self._bn_affine(c, "bn1", None)
+        Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
+        x = _empty((N, Hp, Wp, 64), c)
+        call("isic_bn_relu_maxpool3x3s2_fwd_bf16", c, st0[2], st0[3], x, None, N, Ho, Wo, 64, Hp, Wp)
+        for pre, ds in self.blocks[:2 * int(stage)]:
+            x, _ = self.block_forward(x, pre, ds)
+        N, Hf, Wf, Cf = x.shape
+        return x.float().view(N, Hf * Wf, Cf)
+
     def _bn_names(self):
         names = ["bn1"]
         for pre, ds in self.blocks:
