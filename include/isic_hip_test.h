@@ -18,6 +18,8 @@ extern "C" {
  *   tens     64 -> 64 3x3 layers: 0 shipped default, 1 generic kernel, 2 tile-per-block halo kernel, 3 persistent halo kernel
  *   hundreds >= 128-channel 3x3 stride-1 layers (conv_halo.hip, pixels staged once for all nine taps):
  *            0 shipped default, 1 never, 2 wherever the kernel supports the shape
+ *   thousands persistent short-K kernel (conv_pgemm.hip: strided 3x3, its data gradient, 1x1 downsample):
+ *            0 shipped default, 1 never, 2 wherever the kernel supports the shape (Cout % 128 == 0)
  * variant = 0 is exactly isic_conv2d_igemm_bf16. */
 int isic_test_conv2d_igemm_variant_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int Hin, int Win,
                                         int Cin, int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad,

@@ -293,19 +293,24 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
       }
     }
     if (STATS) {
-      // lanes of one fg group (a DPP row of 16) hold the same 8 channels for 16 different pixels; the four wm waves of
-      // a channel half meet in LDS (fp32 per block, fp64 across blocks)
+      // lanes of one fg group (a DPP row of 16) hold the same 8 channels for 16 different pixels: every lane ends with
+      // the row totals of the 16 values (8 sums, 8 sums of squares) of a channel group, and lane fr contributes value
+      // #fr -- ONE 64-lane LDS atomic per channel group instead of 16 four-lane ones; the four wm waves of a channel
+      // half meet in LDS (fp32 per block, fp64 across blocks)
+      unsigned sb = (unsigned)(wn * 64 + fg * 8 + (fr >> 3) * 128 + (fr & 7));
+      asm volatile("" : "+v"(sb));
+      lds_float* sp = stats_lds + sb;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t) {
+        float mine = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           const float sv = halo_row16_sum(s8[t][c]), qv = halo_row16_sum(q8[t][c]);
-          if (fr == 0) {
-            const int ch = wn * 64 + t * 32 + fg * 8 + c;
-            __hip_atomic_fetch_add(stats_lds + ch, sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(stats_lds + 128 + ch, qv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
+          mine = fr == c ? sv : mine;
+          mine = fr == 8 + c ? qv : mine;
         }
+        __hip_atomic_fetch_add(sp + t * 32, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
     }
   }
   }   // MFMA waves

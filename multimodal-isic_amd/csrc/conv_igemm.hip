@@ -37,46 +37,13 @@
 #include <mutex>
 
 #include "common.h"
+#include "conv_args.h"
 
 namespace {
 
+using namespace isic_conv;
+
 constexpr int BK = 64;  // bf16 elements per K-tile (128 bytes per LDS row)
-
-struct ConvArgs {
-  const unsigned short* in;
-  const unsigned short* w;
-  unsigned short* out;
-  const unsigned short* addend;
-  double* stat_sum;
-  double* stat_sumsq;
-  int stat_slots;
-  int N, Hin, Win, Cin, Hout, Wout, Cout, Kh, Kw, up, down_shift, pad;
-  // output sub-grid of this launch: (ho, wo) = (oh0 + ostep*hs, ow0 + ostep*ws), hs < Hs, ws < Ws
-  int Hs, Ws, oh0, ow0, ostep;
-  // taps of this launch: kh = kh0 + kstep*i (i < nkh), kw = kw0 + kstep*j (j < nkw)
-  int kh0, kw0, kstep, nkh, nkw;
-  int M;        // N*Hs*Ws
-  int Ktiles;   // nkh*nkw*Cin/64
-  int ctiles;   // Cin/64
-  unsigned long long magic_hw, magic_w;   // floor(2^40/d)+1 for d = Hs*Ws and d = Ws (M < 2^24)
-};
-
-// the (up to four) output-parity classes of a strided data gradient run as ONE launch: blockIdx.z picks the class
-struct ConvArgsN {
-  ConvArgs c[4];
-  int n;
-};
-
-__device__ __forceinline__ unsigned fastdiv40(unsigned n, unsigned long long magic) {
-  return (unsigned)(((unsigned long long)n * magic) >> 40);
-}
-// bit t set iff lo <= base + t < hi, for t in [0, cnt)  (cnt <= 16)
-__device__ __forceinline__ unsigned range_mask(int base, int lo, int hi, int cnt) {
-  int t0 = lo - base, t1 = hi - base;
-  t0 = t0 < 0 ? 0 : t0;
-  t1 = t1 > cnt ? cnt : t1;
-  return t1 > t0 ? (((1u << t1) - 1u) & ~((1u << t0) - 1u)) : 0u;
-}
 
 __device__ __forceinline__ float bfbits(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
 
@@ -444,15 +411,18 @@ bool isic_conv_halo_supported(int N, int H, int W, int Cin, int Cout);
 int isic_conv_halo_launch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int H, int W, int Cin, int Cout,
                           const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots,
                           hipStream_t stream);
+int isic_conv_pgemm_launch(const isic_conv::ConvArgsN& classes, hipStream_t stream);
 
 namespace {
 
 // `variant` (include/isic_hip_test.h): 0 = the shipped dispatch.  Otherwise, decimal digits
 //   units: staging MODE of the generic kernel + 1 (0 = default), tens: 64 -> 64 kernels (0 default, 1 generic kernel,
 //   2 tile per block, 3 persistent), hundreds: pixels-staged-once kernel of conv_halo.hip (0 = where profitable,
-//   1 = never, 2 = wherever it is supported).  No global state: the choice travels with the call.
+//   1 = never, 2 = wherever it is supported), thousands: persistent short-K kernel of conv_pgemm.hip (0 = where
+//   profitable: strided and 1x1 layers, 1 = never, 2 = wherever it is supported).  No global state: the choice travels
+//   with the call.
 struct ConvVariant {
-  int mode, c64, halo;
+  int mode, c64, halo, pgemm;
 };
 inline ConvVariant decode_variant(int v) {
   ConvVariant r;
@@ -460,6 +430,7 @@ inline ConvVariant decode_variant(int v) {
   r.mode = m == 0 ? kDefaultConvMode : m - 1;
   r.c64 = c == 0 ? kDefaultConvC64 : c - 1;
   r.halo = (v / 100) % 10;
+  r.pgemm = (v / 1000) % 10;
   return r;
 }
 
@@ -477,9 +448,10 @@ int conv2d_dispatch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N,
                     const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots, int variant,
                     void* stream) {
   ISIC_CHECK_ARG(in && w && out);
-  ISIC_CHECK_ARG(variant >= 0 && variant < 1000);
+  ISIC_CHECK_ARG(variant >= 0 && variant < 10000);
   const ConvVariant cv = decode_variant(variant);
-  ISIC_CHECK_ARG(cv.mode >= 0 && cv.mode <= 5 && cv.c64 >= 0 && cv.c64 <= 2 && cv.halo >= 0 && cv.halo <= 2);
+  ISIC_CHECK_ARG(cv.mode >= 0 && cv.mode <= 5 && cv.c64 >= 0 && cv.c64 <= 2 && cv.halo >= 0 && cv.halo <= 2 &&
+                 cv.pgemm >= 0 && cv.pgemm <= 2);
   ISIC_CHECK_ARG(N > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && Kh > 0 && Kw > 0 && up > 0);
   ISIC_CHECK_ARG(down == 1 || down == 2);
   ISIC_CHECK_ARG((stat_sum == nullptr) == (stat_sumsq == nullptr));
@@ -531,6 +503,12 @@ int conv2d_dispatch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N,
       all.c[all.n++] = a;
     }
   if (all.n == 0) return ISIC_OK;
+  // short-K layers (stride-2 3x3 and its data gradient, 1x1 downsample): persistent blocks, register epilogue
+  if (Cout % 128 == 0 && !(stat_sum && addend) && cv.pgemm != 1 &&
+      (cv.pgemm == 2 || up != 1 || (down != 1 && Kh * Kw > 1) || (Kh == 1 && Kw == 1 && down == 1))) {
+    const int rc = isic_conv_pgemm_launch(all, s);
+    return rc != ISIC_OK ? rc : isic_launch_status();
+  }
   {
     int rc;
     const int mode = cv.mode;

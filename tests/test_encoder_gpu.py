@@ -205,6 +205,66 @@ def test_conv_halo_kernel(case):
         bf16_close(from_nhwc(got), want, f"halo conv {case}")
 
 
+PGEMM_CASES = [  # N, Hin, Win, Cin, Cout, k, stride, pad -- forward geometry; the data gradient runs the transposed problem
+    (3, 10, 10, 64, 128, 3, 2, 1),        # one partial tile, odd output size
+    (300, 28, 28, 64, 128, 3, 2, 1),      # layer2.0 conv1: 230 tiles over the persistent blocks, 9 K-tiles
+    (300, 28, 28, 64, 128, 1, 2, 0),      # layer2.0 downsample: ONE K-tile per tile (the ring wraps across tiles)
+    (260, 14, 14, 128, 256, 3, 2, 1),     # layer3.0: two output slices forward, one slice x four parity classes backward
+    (260, 14, 14, 128, 256, 1, 2, 0),
+    (64, 9, 11, 256, 512, 3, 2, 1),       # non-square, odd sizes: parity classes of different shapes
+    (5, 7, 7, 256, 256, 3, 1, 1),         # a stride-1 layer forced through the kernel (variant digit 2)
+]
+
+
+@pytest.mark.parametrize("case", PGEMM_CASES)
+def test_conv_pgemm_kernel(case):
+    """conv_pgemm.hip (persistent blocks, staging two K-tiles ahead across tile boundaries, register epilogue) against
+    the one-tile-per-block implicit GEMM it replaces for the strided / 1x1 layers: forward with fused statistics, data
+    gradient (all output-parity classes in one launch) with and without the addend join.  Same operands, same K order
+    per output -> the two kernels agree bit for bit; small cases are also checked against torch's fp32 convolution."""
+    from isic_hip.lib import call
+    N, H, W, Ci, Co, k, s, p = case
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(N, H, W, Ci, generator=g).to(DEV).to(BF)
+    dy = torch.randn(N, Ho, Wo, Co, generator=g).to(DEV).to(BF)
+    add = torch.randn(N, H, W, Ci, generator=g).to(DEV).to(BF)
+    w = torch.randn(Co, Ci, k, k, generator=g) / np.sqrt(Ci * k * k)
+    wf = torch.empty(Co * Ci * k * k, device=DEV, dtype=BF)
+    wd = torch.empty_like(wf)
+    call("isic_conv_weight_prep_bf16", krsc(w), wf, wd, Co, Ci, k, k)
+    slots = 32
+
+    def fwd(variant):
+        out = torch.empty(N, Ho, Wo, Co, device=DEV, dtype=BF)
+        acc = torch.zeros(2, slots, Co, device=DEV, dtype=torch.float64)
+        call("isic_test_conv2d_igemm_variant_bf16", x, wf, out, N, H, W, Ci, Ho, Wo, Co, k, k, s, 1, p, None, acc[0], acc[1],
+             slots, variant)
+        return out, acc.sum(1)
+
+    def dgrad(variant, addend):
+        dx = torch.empty(N, H, W, Ci, device=DEV, dtype=BF)
+        call("isic_test_conv2d_igemm_variant_bf16", dy, wd, dx, N, Ho, Wo, Co, H, W, Ci, k, k, 1, s, k - 1 - p,
+             add if addend else None, None, None, 0, variant)
+        return dx
+    ref, racc = fwd(1100)                 # thousands 1 / hundreds 1: the one-tile-per-block kernel
+    got, gacc = fwd(2100)                 # thousands 2: the persistent kernel wherever supported
+    torch.cuda.synchronize()
+    assert torch.equal(ref.view(torch.int16), got.view(torch.int16)), f"fwd {case}: {int((ref != got).sum())} values differ"
+    o = got.float().reshape(-1, Co).double()
+    assert_close(gacc[0].cpu(), o.sum(0).cpu(), rtol=1e-5, atol=1e-3, what="fused sum")
+    assert_close(gacc[1].cpu(), (o * o).sum(0).cpu(), rtol=1e-5, atol=1e-3, what="fused sumsq")
+    if Ci % 128 == 0:                     # the data gradient's output channels = Cin must fill a 128-wide slice
+        for addend in (False, True):
+            a, b = dgrad(1100, addend), dgrad(2100, addend)
+            torch.cuda.synchronize()
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16)), \
+                f"dgrad {case} addend={addend}: {int((a != b).sum())} values differ"
+    if N * H * W <= 8192:
+        xr, wr = x.float().cpu().permute(0, 3, 1, 2), w.bfloat16().float()
+        bf16_close(from_nhwc(got), F.conv2d(xr, wr, None, s, p), f"pgemm fwd {case}")
+
+
 @pytest.mark.parametrize("C", [64, 128])
 @pytest.mark.parametrize("shape", [(2, 13, 37), (40, 56, 56), (150, 56, 56), (37, 28, 40)])
 def test_conv_wgrad_all_taps_kernels(shape, C):
