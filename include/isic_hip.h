@@ -231,13 +231,6 @@ int isic_gcn_csr_build(const int64_t* src, const int64_t* dst, const float* edge
 int isic_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, const float* bias,
                       float* out, int64_t n_rows, int F, float alpha, const float* addend, float addend_scale,
                       void* stream);
-/* The same product for a batch of SMALL graphs (block-diagonal CSR: every neighbour of a row belongs to the row's own
- * graph): graph_offsets[num_graphs+1] (int64 row ranges), max_nodes = the largest graph.  Every graph's rows are staged
- * once into LDS per 64-feature chunk and the neighbour gather reads LDS instead of L2; falls back to isic_spmm_csr_f32
- * when F % 64 != 0 or max_nodes > 256.  Results are bit-identical to isic_spmm_csr_f32 (same edge order per row). */
-int isic_spmm_csr_graphs_f32(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, const float* bias,
-                             float* out, int64_t n_rows, int F, float alpha, const float* addend, float addend_scale,
-                             const int64_t* graph_offsets, int num_graphs, int max_nodes, void* stream);
 
 /* Graph attention (PyG GATConv(heads=H, concat=True, dropout=p) as called at
  * 05_train_gnns.py:83-86) on the GCN-mode CSR (self loops re-added; `val` unused):

@@ -9,8 +9,6 @@
 // segmented sum owned by one wave per destination row: no atomics, deterministic order (edges keep
 // their edge_index order inside a row), every neighbour row is read with one coalesced wave-wide
 // load, every output row written once.  The backward pass is the same kernel on the transposed CSR.
-#include <mutex>
-
 #include "common.h"
 
 namespace {
@@ -360,94 +358,6 @@ inline int grid_for(int64_t n, int block, int cap = 4096) {
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-// ----------------------------------------------------------------- graph-resident SpMM
-// A batch of SMALL graphs (a patch graph has 196 nodes) is block-diagonal: every neighbour of a row lives in the row's
-// own graph.  One 256-thread block owns (graph, 64-feature chunk): the graph's rows of that chunk are staged ONCE into
-// LDS by LDS-DMA (n x 256 B: 49 KB at n = 196, three blocks per CU), and every neighbour-row gather -- E x 256 B, 9x
-// the compulsory bytes at k = 8 -- is then an LDS read instead of an L2 round trip.  A group of 16 lanes (16 B each)
-// owns an output row: the indices / weights of up to 16 edges arrive in one coalesced load and are broadcast by lane
-// shuffles; the neighbour rows are 256-B ds_read_b128 group reads (conflict-free: each row starts on bank 0 and the
-// instruction's 16-lane service groups take disjoint quarters of two rows).  Accumulation order per row = edge order:
-// bit-identical to the global-gather kernels above.
-constexpr int GL_MAXN = 256;                       // rows of one graph that fit the LDS image (64 KB)
-__device__ __forceinline__ void graph_glds16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
-__global__ __launch_bounds__(256) void spmm_graph_lds_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
-                                                              const float* __restrict__ val, const float* __restrict__ x,
-                                                              const float* __restrict__ bias, float* __restrict__ out,
-                                                              const int64_t* __restrict__ goffs, int F, int chunks, float alpha,
-                                                              const float* __restrict__ addend, float addend_scale) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)gsm;
-  const int g = blockIdx.x / chunks, fc = blockIdx.x - g * chunks;
-  const int64_t r0 = goffs[g];
-  const int n = (int)(goffs[g + 1] - r0);
-  if (n <= 0) return;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int gl = lane & 15, grp = lane >> 4;
-  const float* xc = x + fc * 64 + gl * 4;            // this lane's 16 bytes of a row's chunk
-  // ---- stage the graph's rows: one DMA = 4 rows x 256 B (lane -> row 4q + grp, 16-byte piece gl), lane-linear image
-  const int pieces = (n + 3) >> 2;
-  for (int q = wave; q < pieces; q += 4) {
-    const int r = min(4 * q + grp, n - 1);           // the tail piece re-reads the last row (its LDS rows are never used)
-    graph_glds16(xc + (r0 + r) * (int64_t)F, lds0 + q * 1024);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  // ---- rows: group (wave, grp) takes rows gid, gid + 16, ...
-  const int g0 = lane - gl;
-  for (int i = wave * 4 + grp; i < ((n + 15) & ~15); i += 16) {        // uniform trip count per wave (shuffles below)
-    const bool row_ok = i < n;
-    const int b = row_ok ? rowptr[r0 + i] : 0, deg = row_ok ? rowptr[r0 + i + 1] - b : 0;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int base = 0;; base += 16) {
-      const int cnt = min(16, deg - base);
-      int maxcnt = cnt;
-      maxcnt = max(maxcnt, __shfl_xor(maxcnt, 16, 64));
-      maxcnt = max(maxcnt, __shfl_xor(maxcnt, 32, 64));
-      if (maxcnt <= 0) break;
-      int c = 0;
-      float w = 0.f;
-      if (gl < cnt) { c = col[b + base + gl] - (int)r0; w = val[b + base + gl]; }
-      for (int j = 0; j < maxcnt; j += 4) {
-        int cj[4];
-        float wj[4];
-        float4 xv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          cj[u] = __shfl(c, g0 + ((j + u) & 15), 64);
-          wj[u] = __shfl(w, g0 + ((j + u) & 15), 64);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          xv[u] = *reinterpret_cast<const float4*>(gsm + (j + u < cnt ? cj[u] : 0) * 256 + gl * 16);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (j + u < cnt) {
-            acc.x += wj[u] * xv[u].x; acc.y += wj[u] * xv[u].y; acc.z += wj[u] * xv[u].z; acc.w += wj[u] * xv[u].w;
-          }
-      }
-    }
-    if (row_ok) {
-      const int64_t o_off = (r0 + i) * (int64_t)F + fc * 64 + gl * 4;
-      float4 o = make_float4(alpha * acc.x, alpha * acc.y, alpha * acc.z, alpha * acc.w);
-      if (bias) {
-        const float4 bv = *reinterpret_cast<const float4*>(bias + fc * 64 + gl * 4);
-        o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
-      }
-      if (addend) {
-        const float4 av = *reinterpret_cast<const float4*>(addend + o_off);
-        o.x += addend_scale * av.x; o.y += addend_scale * av.y; o.z += addend_scale * av.z; o.w += addend_scale * av.w;
-      }
-      *reinterpret_cast<float4*>(out + o_off) = o;
-    }
-  }
-}
-
 }  // namespace
 
 extern "C" {
@@ -540,31 +450,6 @@ int isic_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* va
     hipLaunchKernelGGL(spmm_kernel<2>, grid, dim3(256), 0, s, rowptr, col, val, x, bias, out, n_rows, F, alpha, addend, addend_scale);
   else
     hipLaunchKernelGGL(spmm_kernel<1>, grid, dim3(256), 0, s, rowptr, col, val, x, bias, out, n_rows, F, alpha, addend, addend_scale);
-  return isic_launch_status();
-}
-
-
-int isic_spmm_csr_graphs_f32(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, const float* bias,
-                             float* out, int64_t n_rows, int F, float alpha, const float* addend, float addend_scale,
-                             const int64_t* graph_offsets, int num_graphs, int max_nodes, void* stream) {
-  ISIC_CHECK_ARG(n_rows >= 0 && F > 0 && num_graphs >= 0 && max_nodes >= 0);
-  if (n_rows == 0 || num_graphs == 0) return ISIC_OK;
-  ISIC_CHECK_ARG(rowptr && col && val && x && out && graph_offsets);
-  const bool al16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(bias) |
-                      reinterpret_cast<uintptr_t>(addend)) & 15) == 0;
-  if (F % 64 != 0 || max_nodes > GL_MAXN || max_nodes < 1 || !al16 || (int64_t)num_graphs * (F / 64) > 0x7FFFFFFFLL)
-    return isic_spmm_csr_f32(rowptr, col, val, x, bias, out, n_rows, F, alpha, addend, addend_scale, stream);
-  const int lds = ((max_nodes + 3) / 4) * 1024;
-  static std::once_flag once;
-  static hipError_t attr_rc = hipSuccess;
-  std::call_once(once, [] {
-    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_graph_lds_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (GL_MAXN / 4) * 1024);
-  });
-  if (attr_rc != hipSuccess) return ISIC_ERR_LAUNCH;
-  const int chunks = F / 64;
-  hipLaunchKernelGGL(spmm_graph_lds_kernel, dim3((unsigned)(num_graphs * chunks)), dim3(256), lds, as_stream(stream), rowptr,
-                     col, val, x, bias, out, graph_offsets, F, chunks, alpha, addend, addend_scale);
   return isic_launch_status();
 }
 

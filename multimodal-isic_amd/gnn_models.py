@@ -217,7 +217,7 @@ class GraphMIL(nn.Module):
         """CSR aggregation mode the layers need (``GraphBatch`` mode), ``None`` for the graph-free 'mlp'."""
         return _GRAPH_MODE.get(self.gnn_type)
 
-    def _graph(self, edge_index, edge_weight, n_nodes, graph, offs=None):
+    def _graph(self, edge_index, edge_weight, n_nodes, graph):
         if self.gnn_type == 'mlp':
             return None
         if graph is not None:
@@ -229,9 +229,7 @@ class GraphMIL(nn.Module):
             raise ValueError(f"gnn_type '{self.gnn_type}' needs edge_index")
         mode = _GRAPH_MODE[self.gnn_type]
         # 05:184-187 passes edge_weight to gcn / gcnii only
-        gb = GraphBatch(edge_index, n_nodes, edge_weight if self.gnn_type in ("gcn", "gcnii") else None, mode=mode)
-        gb.offsets = offs             # graphs of a batch never share edges: the LDS-resident SpMM may be used
-        return gb
+        return GraphBatch(edge_index, n_nodes, edge_weight if self.gnn_type in ("gcn", "gcnii") else None, mode=mode)
 
     def forward(self, x, edge_index=None, edge_weight=None, offsets=None, graph=None):
         """x[N, D] (+ edge_index[2, E]) -> (probs[C], attention_weights[N, heads]) as the reference
@@ -240,7 +238,7 @@ class GraphMIL(nn.Module):
         single = offsets is None
         offs = BagOffsets.single(x.shape[0], x.device) if single else as_offsets(offsets, x.device)
         clk, tr = self.dropout_clock, self.training
-        g = self._graph(edge_index, edge_weight, x.shape[0], graph, offs)
+        g = self._graph(edge_index, edge_weight, x.shape[0], graph)
         x_in = ops.linear(x, self.input_proj.weight, self.input_proj.bias) if self.input_proj is not None else x
         h, x0 = x_in, x_in
         p_drop = self.gnn_dropout.p

@@ -52,7 +52,6 @@ class GraphBatch:
         nbytes = int(call("isic_gcn_csr_workspace_bytes", n, E))
         ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
         self.mode = mode
-        self.offsets = None            # BagOffsets of the graphs of a batch (block-diagonal): enables the LDS-resident SpMM
         call("isic_gcn_csr_build", ei[0], ei[1], ew, E, n, self.MODES[mode], self.rowptr, self.col, self.val,
              self.rowptr_t, self.col_t, self.val_t, self.perm_t, ws, nbytes)
 
@@ -64,7 +63,6 @@ def _graph_from_parts(n_nodes, num_edges, mode, parts):
         raise ValueError(f"unknown graph mode '{mode}'")
     g = GraphBatch.__new__(GraphBatch)
     g.n_nodes, g.num_edges, g.mode = int(n_nodes), int(num_edges), mode
-    g.offsets = None
     for k in ("rowptr", "col", "val", "rowptr_t", "col_t", "val_t", "perm_t"):
         t = parts[k]
         want = torch.float32 if k.startswith("val") else torch.int32
@@ -79,19 +77,6 @@ def _graph_from_parts(n_nodes, num_edges, mode, parts):
 GraphBatch.from_parts = staticmethod(_graph_from_parts)
 
 
-def _spmm_launch(graph, transposed, x, bias, out, alpha, addend, addend_scale):
-    """CSR (or transposed CSR) product; graphs that carry their row ranges (``graph.offsets``: a batch of small
-    block-diagonal graphs) take the LDS-resident kernel."""
-    rp, co, va = (graph.rowptr_t, graph.col_t, graph.val_t) if transposed else (graph.rowptr, graph.col, graph.val)
-    n, F = x.shape
-    offs = getattr(graph, "offsets", None)
-    if offs is not None and offs.total == n and offs.max_bag <= 256 and F % 64 == 0:
-        call("isic_spmm_csr_graphs_f32", rp, co, va, x, bias, out, n, F, alpha, addend, addend_scale, offs.device,
-             offs.num_bags, offs.max_bag)
-    else:
-        call("isic_spmm_csr_f32", rp, co, va, x, bias, out, n, F, alpha, addend, addend_scale)
-
-
 class SpmmFn(torch.autograd.Function):
     """out = alpha * A^ x (+ bias) (+ addend_scale * addend); backward through the transposed CSR."""
 
@@ -103,8 +88,8 @@ class SpmmFn(torch.autograd.Function):
         if n != graph.n_nodes:
             raise ValueError(f"x has {n} rows, graph has {graph.n_nodes} nodes")
         out = torch.empty_like(x2)
-        _spmm_launch(graph, False, x2, _f32c(bias) if bias is not None else None, out, float(alpha),
-                     _f32c(addend) if addend is not None else None, float(addend_scale))
+        call("isic_spmm_csr_f32", graph.rowptr, graph.col, graph.val, x2, _f32c(bias) if bias is not None else None, out,
+             n, F, float(alpha), _f32c(addend) if addend is not None else None, float(addend_scale))
         ctx.graph, ctx.alpha, ctx.addend_scale = graph, float(alpha), float(addend_scale)
         ctx.has_bias, ctx.has_addend = bias is not None, addend is not None
         return out
@@ -116,7 +101,8 @@ class SpmmFn(torch.autograd.Function):
         dx = db = da = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(dy)
-            _spmm_launch(g, True, dy, None, dx, ctx.alpha, None, 0.0)
+            call("isic_spmm_csr_f32", g.rowptr_t, g.col_t, g.val_t, dy, None, dx, dy.shape[0], dy.shape[1], ctx.alpha,
+                 None, 0.0)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy)
         if ctx.has_addend and ctx.needs_input_grad[4]:

@@ -268,7 +268,6 @@ class GraphStore:
             n = int(self.x[i].shape[0])
             if self.needs_graph and i not in self._single:
                 self._single[i] = GraphBatch(self.ei[i], n, mode=self.mode)
-                self._single[i].offsets = BagOffsets.single(n, self.device)
             return self.x[i], BagOffsets.single(n, self.device), self._single.get(i)
         if self._xstack is not None:
             n, D = int(self._xstack.shape[1]), int(self._xstack.shape[2])
@@ -285,8 +284,6 @@ class GraphStore:
             else:
                 ei = torch.cat([self.ei[i] + int(o) for i, o in zip(idx, offs.host[:-1])], dim=1)
                 graph = GraphBatch(ei, offs.total, mode=self.mode)
-        if graph is not None:
-            graph.offsets = offs                  # block-diagonal batch: the LDS-resident SpMM may be used
         out = (x, offs, graph)
         if cache:
             self._chunks[key] = out

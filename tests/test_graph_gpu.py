@@ -297,35 +297,6 @@ def test_graphmil_rejects_unknown_type_and_builds_all_reference_types():
         GraphMIL(64, t, 64, 2)
 
 
-@pytest.mark.parametrize("mode", ["gcn", "mean"])
-def test_graph_resident_spmm_is_bit_identical(mode):
-    """`isic_spmm_csr_graphs_f32` (a graph's rows staged once in LDS per 64-feature chunk) == `isic_spmm_csr_f32`
-    (global gather) bit for bit, forward and transposed, with bias / alpha / addend, on a ragged batch (graph sizes
-    1 ... 196, not multiples of the 4-row DMA piece) -- and it falls back when F is not a multiple of 64."""
-    from isic_hip.bags import BagOffsets
-    from isic_hip.graph import GraphBatch, _spmm_launch
-    gen = torch.Generator().manual_seed(12)
-    sizes = [196, 1, 7, 64, 33, 196, 2, 255]
-    offs_h = np.concatenate([[0], np.cumsum(sizes)])
-    eis = [_rand_graph(n, 6 * n, gen, self_loops=True) if n > 1 else torch.zeros(2, 0, dtype=torch.long) for n in sizes]
-    ei = torch.cat([e + int(o) for e, o in zip(eis, offs_h[:-1])], dim=1).to(DEV)
-    T = int(offs_h[-1])
-    offs = BagOffsets(offs_h, torch.device(DEV))
-    for F_ in (64, 128, 192, 96):
-        gb = GraphBatch(ei, T, mode=mode)
-        x = torch.randn(T, F_, generator=gen).to(DEV)
-        bias = torch.randn(F_, generator=gen).to(DEV)
-        add = torch.randn(T, F_, generator=gen).to(DEV)
-        for transposed in (False, True):
-            ref, got = torch.empty_like(x), torch.empty_like(x)
-            gb.offsets = None
-            _spmm_launch(gb, transposed, x, bias, ref, 0.7, add, 0.3)
-            gb.offsets = offs
-            _spmm_launch(gb, transposed, x, bias, got, 0.7, add, 0.3)
-            torch.cuda.synchronize()
-            assert torch.equal(ref, got), (F_, transposed, float((ref - got).abs().max()))
-
-
 def test_heterophily_measures_vs_reference_golden_and_oracle():
     """`measure_heterophily.compute_edge_heterophily` (HIP edge kernel + device class bookkeeping + batched
     eigensolve) vs the reference's own numpy function on a 196-node image (tests/golden/heterophily.npz: raw edge
