@@ -10,8 +10,6 @@
 // a 16-deep chunk lane-group g (= lane>>4) supplies k = 4g + j at step j for A
 // and for B alike (any permutation of k is a valid summation order as long as
 // both operands use it).
-#include <mutex>
-
 #include "common.h"
 
 namespace {
@@ -133,129 +131,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// 128 x 128 x 32 tile for the large products of the GNN / MIL paths (node-feature projections over tens of thousands
-// of nodes, their data and weight gradients).  The 64 x 64 x 16 kernel above issues 16 MFMAs per wave between two
-// barriers and runs at ~30 TFLOP/s; here a wave owns 64 x 64 = 4 x 4 MFMA tiles and issues 128 MFMAs per barrier:
-// two LDS stages (next tile's global loads in flight under the multiply, one barrier per K-tile), rows of 32 floats =
-// 128 B with the 16-byte-chunk XOR swizzle (chunk ^ (row & 7)) so that the ds_read_b128 fragment reads of 16 rows x 4
-// k-chunks are conflict-free, k permuted inside a 16-deep chunk exactly as above (lane group g supplies k = 4g + j at
-// step j for both operands).  Same operand conventions, epilogue and split-K as gemm_f32_kernel.
-constexpr int GM = 128, GN = 128, GK = 32;
-
-__global__ __launch_bounds__(256, 2) void gemm_f32_big_kernel(GemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float gsm[];      // 2 stages x (A 128x32 | B 128x32)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * GM, n0 = blockIdx.y * GN;
-  const int fr = lane & 15, fg = lane >> 4;
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int kbeg = blockIdx.z * a.klen;                            // klen is a multiple of GK
-  const int kend = min(a.K, kbeg + a.klen);
-  const int nk = (kend - kbeg + GK - 1) / GK;
-  // staging: 4 float4 per operand per thread.  k-contiguous source: (row = q*32 + tid/8, k4 = (tid&7)*4);
-  // row-contiguous source: (k = q*8 + tid/32, r4 = (tid&31)*4)
-  float4 ra[4], rb[4];
-  auto gload = [&](int kt) {
-    const int k0 = kbeg + kt * GK;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (!a.transA) ra[q] = load4(a.A, a.lda, m0 + q * 32 + (tid >> 3), k0 + (tid & 7) * 4, a.M, kend, a.vecA);
-      else ra[q] = load4(a.A, a.lda, k0 + q * 8 + (tid >> 5), m0 + (tid & 31) * 4, kend, a.M, a.vecA);
-      if (a.transB) rb[q] = load4(a.B, a.ldb, n0 + q * 32 + (tid >> 3), k0 + (tid & 7) * 4, a.N, kend, a.vecB);
-      else rb[q] = load4(a.B, a.ldb, k0 + q * 8 + (tid >> 5), n0 + (tid & 31) * 4, kend, a.N, a.vecB);
-    }
-  };
-  // element (row, k) lives at float index row*32 + ((k>>2) ^ (row & 7))*4 + (k & 3)
-  auto lstore = [&](float* As, float* Bs) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (!a.transA) {
-        const int row = q * 32 + (tid >> 3);
-        *reinterpret_cast<float4*>(&As[row * 32 + (((tid & 7) ^ (row & 7)) << 2)]) = ra[q];
-      } else {
-        const int k = q * 8 + (tid >> 5), r = (tid & 31) * 4;
-        const float v[4] = {ra[q].x, ra[q].y, ra[q].z, ra[q].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) As[(r + e) * 32 + (((k >> 2) ^ ((r + e) & 7)) << 2) + (k & 3)] = v[e];
-      }
-      if (a.transB) {
-        const int row = q * 32 + (tid >> 3);
-        *reinterpret_cast<float4*>(&Bs[row * 32 + (((tid & 7) ^ (row & 7)) << 2)]) = rb[q];
-      } else {
-        const int k = q * 8 + (tid >> 5), r = (tid & 31) * 4;
-        const float v[4] = {rb[q].x, rb[q].y, rb[q].z, rb[q].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) Bs[(r + e) * 32 + (((k >> 2) ^ ((r + e) & 7)) << 2) + (k & 3)] = v[e];
-      }
-    }
-  };
-
-  if (nk > 0) {
-    gload(0);
-    lstore(gsm, gsm + GM * GK);
-  }
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    float* As = gsm + (kt & 1) * (GM + GN) * GK;
-    float* Bs = As + GM * GK;
-    const bool more = kt + 1 < nk;
-    if (more) gload(kt + 1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {                               // two 16-deep chunks
-      float4 af[4], bf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ra_ = wm * 64 + i * 16 + fr, rb_ = wn * 64 + i * 16 + fr;
-        af[i] = *reinterpret_cast<const float4*>(&As[ra_ * 32 + (((kk * 4 + fg) ^ (ra_ & 7)) << 2)]);
-        bf[i] = *reinterpret_cast<const float4*>(&Bs[rb_ * 32 + (((kk * 4 + fg) ^ (rb_ & 7)) << 2)]);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-        }
-    }
-    if (more) {
-      float* An = gsm + ((kt + 1) & 1) * (GM + GN) * GK;
-      lstore(An, An + GM * GK);
-    }
-    __syncthreads();
-  }
-
-  // epilogue: C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = n0 + wn * 64 + j * 16 + fr;
-      if (col >= a.N) continue;
-      const float bv = a.bias ? a.bias[col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * 64 + i * 16 + fg * 4 + r;
-        if (row >= a.M) continue;
-        float v = acc[i][j][r] + bv;
-        if (a.act == ISIC_ACT_RELU) v = fmaxf(v, 0.f);
-        else if (a.act == ISIC_ACT_TANH) v = tanhf(v);
-        float* cp = a.C + (size_t)row * a.ldc + col;
-        if (a.ksplit > 1) { atomicAdd(cp, v); continue; }      // C already holds beta * C (gemm_scale_kernel)
-        if (a.beta != 0.f) v += a.beta * (*cp);
-        *cp = v;
-      }
-    }
-}
-
 // C[M,N] *= beta (0: zero fill) ahead of a split-K accumulation
 __global__ void gemm_scale_kernel(float* __restrict__ C, int M, int N, int ldc, float beta) {
   const int64_t n = (int64_t)M * N;
@@ -346,21 +221,18 @@ int isic_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, i
   a.transA = transA; a.transB = transB; a.act = act; a.beta = beta;
   a.vecA = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
   a.vecB = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
-  // large products (>= 96 rows and columns, enough tiles or a long reduction to split): the 128 x 128 x 32 kernel
-  const bool big = M >= 96 && N >= 96 && ((long long)ceil_div(M, GM) * ceil_div(N, GN) >= 48 || K >= 2048);
-  const int tm = big ? GM : BM, tn = big ? GN : BN, tk = big ? GK : BK;
-  dim3 grid(ceil_div(M, tm), ceil_div(N, tn));
+  dim3 grid(ceil_div(M, BM), ceil_div(N, BN));
   ISIC_CHECK_ARG(grid.y <= 65535u);
   // split K when a long reduction meets a small output (weight gradients dW = dY^T X over all the nodes of a batch):
-  // a handful of tiles would otherwise walk tens of thousands of k on a handful of CUs
-  a.ksplit = 1; a.klen = ((K + tk - 1) / tk) * tk;
+  // a handful of 64x64 tiles would otherwise walk tens of thousands of k on a handful of CUs
+  a.ksplit = 1; a.klen = ((K + BK - 1) / BK) * BK;
   const long long tiles = (long long)grid.x * grid.y;
-  if (!bias && act == ISIC_ACT_NONE && K >= 2048 && tiles < (big ? 256 : 512)) {
-    long long want = ((big ? 512 : 1024) + tiles - 1) / tiles;     // ~2 (big: 64 KB of LDS) or ~4 blocks per CU
+  if (!bias && act == ISIC_ACT_NONE && K >= 2048 && tiles < 512) {
+    long long want = (1024 + tiles - 1) / tiles;                   // ~4 blocks per CU
     const long long max_split = K / 256;                           // at least 256 k per split
     if (want > max_split) want = max_split;
     if (want > 1) {
-      a.klen = (int)(((K + want - 1) / want + tk - 1) / tk) * tk;
+      a.klen = (int)(((K + want - 1) / want + BK - 1) / BK) * BK;
       a.ksplit = ceil_div(K, a.klen);
     }
   }
@@ -370,19 +242,7 @@ int isic_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, i
                          ldc, beta);
     grid.z = a.ksplit;
   }
-  if (big) {
-    constexpr int LDS = 2 * (GM + GN) * GK * 4;
-    static std::once_flag once;
-    static hipError_t attr_rc = hipSuccess;
-    std::call_once(once, [] {
-      attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_big_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    });
-    if (attr_rc != hipSuccess) return ISIC_ERR_LAUNCH;
-    hipLaunchKernelGGL(gemm_f32_big_kernel, grid, dim3(256), LDS, as_stream(stream), a);
-  } else {
-    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, as_stream(stream), a);
-  }
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, as_stream(stream), a);
   return isic_launch_status();
 }
 

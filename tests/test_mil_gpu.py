@@ -145,36 +145,3 @@ def test_gemm_split_k_and_chunked_colsum(shape, beta):
     o = o0.clone().to(DEV)
     ops.colsum(x.to(DEV), out=o, beta=beta)
     assert_close(o.cpu(), x.double().sum(0) + beta * o0.double(), rtol=2e-6, atol=1e-4, what=f"colsum {shape} beta={beta}")
-
-
-@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
-@pytest.mark.parametrize("shape", [(1000, 130, 96), (50176 // 8, 128, 768), (257, 129, 33), (384, 512, 128)])
-def test_gemm_large_tile_kernel(ta, tb, shape):
-    """The 128 x 128 x 32 fp32-MFMA kernel (products with >= 96 rows and columns): all four operand transpositions,
-    sizes that are no multiple of the tile in any dimension, bias + ReLU / tanh epilogues, beta accumulation and a
-    strided (row-view) operand, against fp64.  Exact-fp32 products: only the summation order differs (2e-6)."""
-    from isic_hip import ops
-    M, N, K = shape
-    g = torch.Generator().manual_seed(M + N + K)
-    a = torch.randn((K, M) if ta else (M, K), generator=g)
-    b = torch.randn((N, K) if tb else (K, N), generator=g)
-    bias = torch.randn(N, generator=g)
-    A, B = (a.t() if ta else a).double(), (b.t() if tb else b).double()
-    ref = A @ B
-    scale = float(ref.abs().max())
-    out = ops.gemm(a.to(DEV), b.to(DEV), trans_a=ta, trans_b=tb)
-    assert_close(out.cpu(), ref, rtol=2e-6, atol=2e-6 * scale, what=f"gemm {shape} ta={ta} tb={tb}")
-    out = ops.gemm(a.to(DEV), b.to(DEV), trans_a=ta, trans_b=tb, bias=bias.to(DEV), act=ops.ACT_RELU)
-    assert_close(out.cpu(), torch.relu(ref + bias.double()), rtol=2e-6, atol=2e-6 * scale, what="bias + relu")
-    out = ops.gemm(a.to(DEV), b.to(DEV), trans_a=ta, trans_b=tb, bias=bias.to(DEV), act=ops.ACT_TANH)
-    assert_close(out.cpu(), torch.tanh((ref + bias.double()) / 1.0), rtol=1e-5, atol=2e-6, what="bias + tanh")
-    c0 = torch.randn(M, N, generator=g)
-    out = c0.clone().to(DEV)
-    ops.gemm(a.to(DEV), b.to(DEV), trans_a=ta, trans_b=tb, out=out, beta=0.5)
-    assert_close(out.cpu(), ref + 0.5 * c0.double(), rtol=2e-6, atol=2e-6 * scale, what="beta")
-    # an operand that is a column slice of a wider matrix (leading dimension > row length, unaligned start)
-    wide = torch.randn(a.shape[0], a.shape[1] + 5, generator=g).to(DEV)
-    view = wide[:, 3:3 + a.shape[1]]
-    refv = (view.t() if ta else view).double().cpu() @ B
-    assert_close(ops.gemm(view, b.to(DEV), trans_a=ta, trans_b=tb).cpu(), refv, rtol=2e-6, atol=2e-6 * float(refv.abs().max()),
-                 what="strided operand")
