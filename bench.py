@@ -299,18 +299,18 @@ def run_gnn(args, world, rank, dev):
     ei = torch.stack([src.reshape(n_graphs, -1), nn_idx.reshape(n_graphs, -1)], dim=1)      # [G, 2, N*k], local ids
     records = [{"x": x[i], "edge_index": ei[i], "y": int(y[i])} for i in range(n_graphs)]
     store = T.GraphStore(records, dev, True, mode=model.graph_mode)
-    rs = np.random.RandomState(7 + rank)
+    gidx = torch.Generator(device=dev).manual_seed(7 + rank)
 
     timer = KernelTimer()
     timer.install()
 
     def step(i):
-        idx = rs.randint(0, n_graphs, size=Gs).tolist()
+        idx = torch.randint(0, n_graphs, (Gs,), device=dev, generator=gidx)      # drawn on the device: no host -> device copy
         xb, ob, gb = store.batch(idx)
         opt.zero_grad()
         sync.reset()
         probs, _ = model(xb, offsets=ob, graph=gb)
-        loss = ops.cross_entropy_from_probs(probs, store.y_dev[torch.as_tensor(idx, device=dev)])
+        loss = ops.cross_entropy_from_probs(probs, store.y_dev[idx])
         loss.backward()
         sync.finish()
         opt.step(grad_scale=1.0 / world)

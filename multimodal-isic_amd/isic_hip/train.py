@@ -240,10 +240,10 @@ class GraphStore:
             "perm_t": (full.perm_t[:used].view(G, nnz).to(torch.int64) - eoff).to(i32),
         }
 
-    def _stacked_graph(self, idx):
+    def _stacked_graph(self, sel):
+        """``sel``: device int64 tensor of graph indices."""
         st = self._stack
-        n, nnz, B = st["n"], st["nnz"], len(idx)
-        sel = torch.as_tensor(idx, device=self.device, dtype=torch.int64)
+        n, nnz, B = st["n"], st["nnz"], int(sel.numel())
         i32 = torch.int32
         noff = (torch.arange(B, device=self.device, dtype=i32) * n).view(B, 1)
         eoff = (torch.arange(B, device=self.device, dtype=i32) * nnz).view(B, 1)
@@ -258,34 +258,37 @@ class GraphStore:
         return GraphBatch.from_parts(B * n, B * (nnz - (n if self.mode == "gcn" else 0)), self.mode, parts)
 
     def batch(self, idx, cache=False):
-        """(x[sum n, D], offsets, GraphBatch) of the graphs ``idx``; ``cache=True`` keeps the result (evaluation
-        chunks, which repeat every epoch)."""
-        key = tuple(int(i) for i in idx)
-        if cache and key in self._chunks:
+        """(x[sum n, D], offsets, GraphBatch) of the graphs ``idx`` (a list, or an int64 tensor already on the device:
+        no host -> device copy then); ``cache=True`` keeps the result (evaluation chunks, which repeat every epoch)."""
+        on_dev = isinstance(idx, torch.Tensor) and idx.is_cuda
+        key = None if on_dev else tuple(int(i) for i in idx)
+        if cache and key is not None and key in self._chunks:
             return self._chunks[key]
-        if len(idx) == 1:
-            i = idx[0]
+        if not on_dev and len(key) == 1:
+            i = key[0]
             n = int(self.x[i].shape[0])
             if self.needs_graph and i not in self._single:
                 self._single[i] = GraphBatch(self.ei[i], n, mode=self.mode)
             return self.x[i], BagOffsets.single(n, self.device), self._single.get(i)
-        if self._xstack is not None:
+        uniform = self._xstack is not None and (not self.needs_graph or self._stack is not None)
+        if uniform:
+            sel = idx.to(torch.int64) if on_dev else torch.as_tensor(key, device=self.device)
             n, D = int(self._xstack.shape[1]), int(self._xstack.shape[2])
-            x = self._xstack[torch.as_tensor(key, device=self.device)].reshape(-1, D)
-            offs = BagOffsets.uniform(len(key), n, self.device)
+            x = self._xstack[sel].reshape(-1, D)
+            offs = BagOffsets.uniform(int(sel.numel()), n, self.device)
+            graph = self._stacked_graph(sel) if self.needs_graph else None
         else:
-            xs = [self.x[i] for i in idx]
+            if on_dev:
+                key = tuple(int(i) for i in idx.tolist())
+            xs = [self.x[i] for i in key]
             x = torch.cat(xs)
             offs = BagOffsets.from_lengths([int(t.shape[0]) for t in xs], self.device)
-        graph = None
-        if self.needs_graph:
-            if self._stack is not None:
-                graph = self._stacked_graph(key)
-            else:
-                ei = torch.cat([self.ei[i] + int(o) for i, o in zip(idx, offs.host[:-1])], dim=1)
+            graph = None
+            if self.needs_graph:
+                ei = torch.cat([self.ei[i] + int(o) for i, o in zip(key, offs.host[:-1])], dim=1)
                 graph = GraphBatch(ei, offs.total, mode=self.mode)
         out = (x, offs, graph)
-        if cache:
+        if cache and key is not None:
             self._chunks[key] = out
         return out
 
@@ -340,6 +343,7 @@ def train_gnn_fold(model, train_records, val_records, test_records, *, lr=1e-4, 
     for epoch in range(1, epochs + 1):
         model.train()
         order = rng.permutation(len(train_records)).tolist()
+        order_dev = torch.as_tensor(order, device=device)        # ONE upload per epoch; steps slice it on the device
         for s in range(0, len(order), per_step):
             glob = order[s:s + per_step]
             lo, hi = ddp.shard_range(len(glob), rank, world)
@@ -347,9 +351,10 @@ def train_gnn_fold(model, train_records, val_records, test_records, *, lr=1e-4, 
             opt.zero_grad()
             sync.reset()
             if mine:
-                x, offs, g = tr.batch(mine)
+                mine_dev = order_dev[s + lo:s + hi]
+                x, offs, g = tr.batch(mine_dev if len(mine) > 1 else mine)
                 probs, _ = model(x, offsets=offs, graph=g)
-                y = torch.as_tensor(tr.y[mine], device=device)
+                y = tr.y_dev[mine_dev]
                 loss = ops.cross_entropy_from_probs(probs, y) * (len(mine) * world / len(glob))
                 loss.backward()
             _sync_step(opt, sync, world)
