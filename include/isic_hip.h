@@ -297,6 +297,15 @@ int isic_conv_stem_fwd_stats_bf16(const uint16_t* in_nhwc4, const uint16_t* w_st
 int isic_conv_stem_wgrad_bf16(const uint16_t* in_nhwc4, const uint16_t* dy, float* dw, int N, int Hin, int Win,
                               int Hout, int Wout, void* stream);
 int isic_conv_stem_pack_bf16(const float* w_krsc, uint16_t* w_stem, void* stream);
+/* Stem weight gradient straight from the POOLED gradient: dw += conv_wgrad(in, dY) with
+ * dY = BatchNorm(+ReLU) backward (isic_bn_bwd_apply_pooled_bf16) of the 3x3/2 max-pool backward of dy_pooled, formed in
+ * registers from y0 (the stem convolution output), argmax and the reduced sums dgamma / dbeta -- the full-size dY is
+ * neither written nor read.  Also adds dgamma / dbeta into the fp32 gradients when those are given.  Hp, Wp: pooled size. */
+int isic_conv_stem_wgrad_bn_pooled_bf16(const uint16_t* in_nhwc4, const uint16_t* y0, const uint8_t* argmax,
+                                        const uint16_t* dy_pooled, const float* mean, const float* rstd,
+                                        const float* gamma, const float* scale, const float* shift, const double* dgamma,
+                                        const double* dbeta, float* dw, float* dgamma_f32, float* dbeta_f32, int N,
+                                        int Hin, int Win, int Hout, int Wout, int Hp, int Wp, void* stream);
 /* NCHW fp32/bf16 images (the reference's dataset layout, dataset.py:36-40) ->
  * NHWC bf16 with C padded to 4. */
 int isic_nchw_to_nhwc4_bf16(const void* in, int in_is_bf16, uint16_t* out, int N, int C, int H, int W, void* stream);
@@ -353,6 +362,13 @@ int isic_bn_bwd_apply_mask_bf16(const uint16_t* dy, const uint16_t* x, const uin
  * isic_maxpool3x3s2_fwd_bf16. */
 int isic_bn_relu_maxpool3x3s2_fwd_bf16(const uint16_t* x, const float* scale, const float* shift, uint16_t* y,
                                        uint8_t* argmax, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+/* Same, and additionally x_sel[N,Ho,Wo,C] = the RAW input value at each window's argmax (optional).  With it the
+ * BatchNorm backward reduction of the stem is a pass over the pooled tensors only (a window's gradient reaches exactly
+ * its argmax pixel): isic_bn_bwd_reduce_bf16(dy_pooled, x_sel, ..., rows = N*Ho*Wo, relu = 1, scale, shift) gives the
+ * sums of isic_bn_bwd_reduce_pooled_bf16 without reading the 4x larger x. */
+int isic_bn_relu_maxpool3x3s2_fwd_sel_bf16(const uint16_t* x, const float* scale, const float* shift, uint16_t* y,
+                                           uint8_t* argmax, uint16_t* x_sel, int N, int H, int W, int C, int Ho, int Wo,
+                                           void* stream);
 /* BatchNorm(+ReLU, mask recomputed from x) backward whose incoming gradient is the max-pool backward of `dy_pooled`
  * through `argmax`, gathered on the fly: same results as isic_maxpool3x3s2_bwd_bf16 followed by
  * isic_bn_bwd_reduce_bf16 / isic_bn_bwd_apply_bf16 (relu = 1, scale/shift given), without the full-size gradient. */

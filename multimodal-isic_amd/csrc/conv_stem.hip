@@ -13,7 +13,10 @@
 //
 // No counterpart in the reference (encoder un-vendored, save_latent.py:42-60); ResNet-18 layer
 // table: SURVEY.md 8d (conv1: 118 MMAC per 224x224 image).
+#include <type_traits>
+
 #include "common.h"
+#include "pool_grad.h"
 
 namespace {
 
@@ -247,6 +250,167 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(StemArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- weight gradient fed by the POOLED gradient
+// Same tiles and MFMA schedule as conv_stem_wgrad_kernel, but the dY tile is never read from memory: it is the
+// BatchNorm(+ReLU) backward of the 3x3/2 max-pool backward of the pooled gradient, formed in registers from the stem
+// activation y0 (read once, here), the pooled gradient and the argmax codes -- what stem_bn_bwd_apply_kernel would have
+// written (3.3 GB at 2048 images) and this kernel read back.  A thread owns the 2x2 pixels (2a+dy, 2b+dx) of one
+// 8-channel group (pool_grad.h): 8 x 16 tile = 4 x 8 such blocks x 8 groups = 256 threads.  The raw loads of the NEXT
+// tile stay in registers while the current one is multiplied; the arithmetic happens when they are committed to LDS.
+struct StemBnArgs {
+  StemArgs s;                       // s.dy unused
+  const unsigned short* y0;         // [N,Hout,Wout,64] stem convolution output
+  const unsigned char* argmax;      // [N,Hp,Wp,64]
+  const unsigned short* gp;         // [N,Hp,Wp,64] gradient of the pooled activation
+  const float* mean; const float* rstd; const float* gamma; const float* scale; const float* shift;
+  const double* dgamma; const double* dbeta;
+  float* dgamma_f32; float* dbeta_f32;
+  int Hp, Wp;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_stem_wgrad_bn_kernel(StemBnArgs b) {
+  const StemArgs& a = b.s;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[PR * PROW + TH * TW * YROW];
+  __shared__ __attribute__((aligned(16))) float cst[5][64];     // A, B, D of dY = A*dz + B*y0 + D; sc, sh of the ReLU mask
+  unsigned char* Ps = smem;
+  unsigned char* Ys = smem + PR * PROW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fg = lane >> 4, fi = lane & 15, fq = fi >> 2, fp = fi & 3;
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+  const isic_pool::PoolGeom geom{a.Hout, a.Wout, 64, b.Hp, b.Wp};
+
+  if (tid < 64) {
+    const float inv_rows = 1.f / (float)((int64_t)a.N * a.Hout * a.Wout);
+    // dY = k1*(dz - k2 - xh*k3), xh = (y0 - mu)*rs  ==  A*dz + B*y0 + D  (three constants, two FMAs per element)
+    const float rs = b.rstd[tid], mu = b.mean[tid], k1 = b.gamma[tid] * rs;
+    const float k2 = (float)b.dbeta[tid] * inv_rows, k3 = (float)b.dgamma[tid] * inv_rows;
+    cst[0][tid] = k1; cst[1][tid] = -k1 * k3 * rs; cst[2][tid] = k1 * (k3 * rs * mu - k2);
+    cst[3][tid] = b.scale[tid]; cst[4][tid] = b.shift[tid];
+    if (blockIdx.x == 0 && b.dgamma_f32) {
+      b.dgamma_f32[tid] += (float)b.dgamma[tid];
+      b.dbeta_f32[tid] += (float)b.dbeta[tid];
+    }
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // this thread's 2x2 pixel block inside the tile and its channel group
+  const int cg = tid & 7, bl = tid >> 3, al = bl >> 3, bw = bl & 7;
+  u32x2 pre[PATCH_PER_THREAD];
+  u32x4 xr[4];
+  isic_pool::Windows win;
+  auto fetch_dy = [&](int tile) {
+    const int tc = tile < a.total_tiles ? tile : a.total_tiles - 1;       // clamped: always valid addresses
+    const int n = tc / (a.tiles_h * a.tiles_w);
+    const int t2 = tc - n * (a.tiles_h * a.tiles_w);
+    const int oy0 = (t2 / a.tiles_w) * TH, ox0 = (t2 % a.tiles_w) * TW;
+    const int ga = (oy0 >> 1) + al, gb = (ox0 >> 1) + bw;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int hi = min(2 * ga + (p >> 1), a.Hout - 1), wi = min(2 * gb + (p & 1), a.Wout - 1);
+      xr[p] = *reinterpret_cast<const u32x4*>(b.y0 + (((size_t)n * a.Hout + hi) * a.Wout + wi) * 64 + cg * 8);
+    }
+    isic_pool::load_windows(win, b.argmax, b.gp, geom, n, min(ga, b.Hp - 1), min(gb, b.Wp - 1), cg);
+  };
+  // raw loads -> dY values of the 2x2 pixels -> LDS rows [pixel][co]
+  auto commit_dy = [&](int tile) {
+    const int n = tile / (a.tiles_h * a.tiles_w);
+    const int t2 = tile - n * (a.tiles_h * a.tiles_w);
+    const int oy0 = (t2 / a.tiles_w) * TH, ox0 = (t2 % a.tiles_w) * TW;
+    const int ga = (oy0 >> 1) + al, gb = (ox0 >> 1) + bw;
+    const bool inside = (oy0 + TH <= a.Hout) && (ox0 + TW <= a.Wout);    // block-uniform: the usual case
+    auto half = [&](auto HC) {
+      constexpr int H_ = decltype(HC)::value;
+      float g[4][4];
+      isic_pool::windows_to_grad4<H_>(win, geom, ga, gb, g);
+      const int c0 = cg * 8 + H_ * 4;
+      const f32x4 kA = *reinterpret_cast<const f32x4*>(&cst[0][c0]), kB = *reinterpret_cast<const f32x4*>(&cst[1][c0]);
+      const f32x4 kD = *reinterpret_cast<const f32x4*>(&cst[2][c0]), sc = *reinterpret_cast<const f32x4*>(&cst[3][c0]);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(&cst[4][c0]);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int oyl = 2 * al + (p >> 1), oxl = 2 * bw + (p & 1);
+        const bool in = inside || ((oy0 + oyl < a.Hout) && (ox0 + oxl < a.Wout));
+        const unsigned lo = xr[p][2 * H_], hi = xr[p][2 * H_ + 1];
+        const float xv[4] = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xFFFF0000u), __uint_as_float(hi << 16),
+                             __uint_as_float(hi & 0xFFFF0000u)};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float dz = (xv[j] * sc[j] + sh[j] > 0.f) ? g[p][j] : 0.f;
+          o[j] = kA[j] * dz + (kB[j] * xv[j] + kD[j]);
+          if (!inside) o[j] = in ? o[j] : 0.f;
+        }
+        u32x2 v;
+        v[0] = (unsigned)f32_to_bf16_bits(o[0]) | ((unsigned)f32_to_bf16_bits(o[1]) << 16);
+        v[1] = (unsigned)f32_to_bf16_bits(o[2]) | ((unsigned)f32_to_bf16_bits(o[3]) << 16);
+        *reinterpret_cast<u32x2*>(Ys + (oyl * TW + oxl) * YROW + cg * 16 + H_ * 8) = v;
+      }
+    };
+    half(std::integral_constant<int, 0>{});
+    __builtin_amdgcn_sched_barrier(0);                   // keep the two halves' temporaries from overlapping
+    half(std::integral_constant<int, 1>{});
+  };
+  __syncthreads();                                       // constants visible
+  fetch_patch(pre, a, blockIdx.x, tid);
+  fetch_dy(blockIdx.x);
+  for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+    lds_barrier();                                       // previous tile's operands fully consumed
+    commit_patch(Ps, pre, tid);
+    commit_dy(tile);
+    lds_barrier();
+    fetch_patch(pre, a, tile + gridDim.x, tid);
+    fetch_dy(tile + gridDim.x);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int k1 = ks * 32 + 8 * fg + fq, k2 = k1 + 4;   // the two pixel rows this lane addresses
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Ys + k1 * YROW + (i * 16 + 4 * fp) * 2));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Ys + k2 * YROW + (i * 16 + 4 * fp) * 2));
+        s16x8_t t; t.lo = lo; t.hi = hi;
+        af[i] = __builtin_bit_cast(bf16x8, t);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int nt = wave + 4 * j;
+        const int kh = nt >> 1, half = nt & 1;
+        const int khc = kh > 6 ? 6 : kh;
+        const unsigned char* p1 = Ps + (2 * (k1 >> 4) + khc) * PROW + (2 * (k1 & 15) + half * 4 + fp) * 8;
+        const unsigned char* p2 = Ps + (2 * (k2 >> 4) + khc) * PROW + (2 * (k2 & 15) + half * 4 + fp) * 8;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)p1);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)p2);
+        s16x8_t t; t.lo = lo; t.hi = hi;
+        bfr[j] = __builtin_bit_cast(bf16x8, t);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nt = wave + 4 * j;
+      if (nt >= 14) continue;
+      const int kh = nt >> 1, kw = (nt & 1) * 4 + (fi >> 2), c = fi & 3;
+      if (kw >= 7 || c >= 3) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = i * 16 + fg * 4 + r;
+        atomicAdd(a.dw + ((co * 7 + kh) * 7 + kw) * 3 + c, acc[i][j][r]);
+      }
+    }
+}
+
 // fp32 [64][7][7][3] (channels_last memory of the OIHW parameter) -> bf16 [64][7][8][4], zero padded
 __global__ void stem_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ ws) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -302,6 +466,28 @@ int isic_conv_stem_wgrad_bf16(const uint16_t* in_nhwc4, const uint16_t* dy, floa
   if (rc != ISIC_OK) return rc;
   const int grid = a.total_tiles < 512 ? a.total_tiles : 512;
   hipLaunchKernelGGL(conv_stem_wgrad_kernel, dim3(grid), dim3(256), 0, as_stream(stream), a);
+  return isic_launch_status();
+}
+
+int isic_conv_stem_wgrad_bn_pooled_bf16(const uint16_t* in_nhwc4, const uint16_t* y0, const uint8_t* argmax,
+                                        const uint16_t* dy_pooled, const float* mean, const float* rstd,
+                                        const float* gamma, const float* scale, const float* shift, const double* dgamma,
+                                        const double* dbeta, float* dw, float* dgamma_f32, float* dbeta_f32, int N,
+                                        int Hin, int Win, int Hout, int Wout, int Hp, int Wp, void* stream) {
+  ISIC_CHECK_ARG(in_nhwc4 && y0 && argmax && dy_pooled && mean && rstd && gamma && scale && shift && dgamma && dbeta && dw);
+  ISIC_CHECK_ARG(N > 0 && Hin > 0 && Win > 0 && (dgamma_f32 == nullptr) == (dbeta_f32 == nullptr));
+  ISIC_CHECK_ARG(Hp == (Hout + 2 - 3) / 2 + 1 && Wp == (Wout + 2 - 3) / 2 + 1);
+  StemBnArgs b;
+  StemArgs& a = b.s;
+  a.stat_sum = nullptr; a.stat_sumsq = nullptr; a.stat_slots = 1;
+  a.in = in_nhwc4; a.w = nullptr; a.out = nullptr; a.dy = nullptr; a.dw = dw;
+  int rc = stem_args(a, N, Hin, Win, Hout, Wout);
+  if (rc != ISIC_OK) return rc;
+  b.y0 = y0; b.argmax = argmax; b.gp = dy_pooled; b.mean = mean; b.rstd = rstd; b.gamma = gamma; b.scale = scale;
+  b.shift = shift; b.dgamma = dgamma; b.dbeta = dbeta; b.dgamma_f32 = dgamma_f32; b.dbeta_f32 = dbeta_f32;
+  b.Hp = Hp; b.Wp = Wp;
+  const int grid = a.total_tiles < 512 ? a.total_tiles : 512;
+  hipLaunchKernelGGL(conv_stem_wgrad_bn_kernel, dim3(grid), dim3(256), 0, as_stream(stream), b);
   return isic_launch_status();
 }
 

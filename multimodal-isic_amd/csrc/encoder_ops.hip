@@ -7,23 +7,13 @@
 // (BatchNorm2d eps 1e-5, momentum 0.1, biased variance for normalisation, unbiased for the running
 // estimate; MaxPool2d(3, 2, 1) with first-maximum tie breaking; AdaptiveAvgPool2d(1)).
 #include "common.h"
+#include "pool_grad.h"
 
 namespace {
 
-__device__ __forceinline__ void unpack8(const u32x4 v, float (&f)[8]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    f[2 * i] = __uint_as_float(v[i] << 16);
-    f[2 * i + 1] = __uint_as_float(v[i] & 0xFFFF0000u);
-  }
-}
-__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
-  u32x4 v;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    v[i] = (unsigned)f32_to_bf16_bits(f[2 * i]) | ((unsigned)f32_to_bf16_bits(f[2 * i + 1]) << 16);
-  return v;
-}
+using isic_pool::unpack8;
+using isic_pool::pack8;
+using isic_pool::PoolGeom;
 
 // ---------------------------------------------------------------- BatchNorm statistics
 // thread -> channel group cg = tid % (C/8), row lane rl = tid / (C/8); per-thread fp32 partials over
@@ -136,7 +126,6 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
 
 // gather form: each input pixel looks at the <= 2x2 outputs whose window covers it.  Returns the gradient of the
 // 8 channels cg*8.. of input pixel (n, hi, wi), rounded to bf16 like the materialised tensor would be.
-struct PoolGeom { int H, W, C, Ho, Wo; };
 __device__ __forceinline__ void pooled_grad8(const unsigned char* __restrict__ argmax, const unsigned short* __restrict__ dy,
                                              const PoolGeom& g_, int n, int hi, int wi, int cg, float (&out)[8]) {
   float acc[8];
@@ -168,6 +157,9 @@ __device__ __forceinline__ void pooled_grad8(const unsigned char* __restrict__ a
   unpack8(pack8(acc), out);
 }
 
+// MODE: where the ReLU mask comes from -- 0 no ReLU, 1 the output y, 2 recomputed from x (scale, shift), 3 mask bits.
+// Compile-time so that each variant only carries the registers it needs (occupancy is what hides the HBM latency here).
+template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned short* __restrict__ dy,
                                                              const unsigned short* __restrict__ x,
                                                              const unsigned short* __restrict__ y,
@@ -180,7 +172,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned short
                                                              double* __restrict__ dbeta) {
   const int tid = threadIdx.x, cgs = C >> 3, cg = tid % cgs, rl = tid / cgs, rls = 256 / cgs;
   float acc[2][8], mu[8], rs[8], sc[8], sh[8];
-  const bool from_x = relu && scale != nullptr;   // ReLU mask recomputed from x: no read of y
+  constexpr bool from_x = MODE == 2;
+  (void)relu;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     acc[0][j] = 0.f; acc[1][j] = 0.f; mu[j] = mean[cg * 8 + j]; rs[j] = rstd[cg * 8 + j];
@@ -194,14 +187,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned short
     if (from_x) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) yv[j] = xv[j] * sc[j] + sh[j];
-    } else if (relu_mask) {                                // 1 bit per element instead of re-reading the output
+    } else if (MODE == 3) {                                // 1 bit per element instead of re-reading the output
       const unsigned m = relu_mask[r * (C >> 3) + cg];
 #pragma unroll
       for (int j = 0; j < 8; ++j) yv[j] = ((m >> j) & 1u) ? 1.f : 0.f;
-    } else if (relu) unpack8(*reinterpret_cast<const u32x4*>(y + r * C + cg * 8), yv);
+    } else if (MODE == 1) unpack8(*reinterpret_cast<const u32x4*>(y + r * C + cg * 8), yv);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float dz = (relu && !(yv[j] > 0.f)) ? 0.f : g[j];
+      const float dz = (MODE != 0 && !(yv[j] > 0.f)) ? 0.f : g[j];
       acc[0][j] += dz * ((xv[j] - mu[j]) * rs[j]);
       acc[1][j] += dz;
     }
@@ -210,6 +203,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned short
   block_reduce_to_global<2>(acc, C, dst);
 }
 
+template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x, const unsigned short* __restrict__ y,
     const unsigned char* __restrict__ relu_mask,
@@ -219,7 +213,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     unsigned short* __restrict__ dx, unsigned short* __restrict__ d_residual, float* __restrict__ dgamma_f32,
     float* __restrict__ dbeta_f32) {
   const int cgs = C >> 3;
-  const bool from_x = relu && scale != nullptr;
+  constexpr bool from_x = MODE == 2;
+  (void)relu;
   const int64_t nvec = rows * cgs;
   const float inv_rows = 1.f / (float)rows;
   if (blockIdx.x == 0 && dgamma_f32) {
@@ -230,14 +225,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   }
   // per-thread channel constants (grid stride is a multiple of C/8): dx = k1*dz - k2 - xh*k3
   const int cg = threadIdx.x % cgs;
-  float mu[8], rs[8], k1[8], k2[8], k3[8], sc[8], sh[8];
+  // dx = k1*(dz - k2 - xh*k3), xh = (x - mu)*rs  ==  kA*dz + (kB*x + kD): three constants and two FMAs per element
+  float kA[8], kB[8], kD[8], sc[8], sh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = cg * 8 + j;
-    mu[j] = mean[c]; rs[j] = rstd[c];
-    k1[j] = gamma[c] * rs[j];
-    k2[j] = (float)dbeta[c] * inv_rows;
-    k3[j] = (float)dgamma[c] * inv_rows;
+    const float mu = mean[c], rs = rstd[c], k1 = gamma[c] * rs;
+    const float k2 = (float)dbeta[c] * inv_rows, k3 = (float)dgamma[c] * inv_rows;
+    kA[j] = k1; kB[j] = -k1 * k3 * rs; kD[j] = k1 * (k3 * rs * mu - k2);
     sc[j] = from_x ? scale[c] : 0.f; sh[j] = from_x ? shift[c] : 0.f;
   }
 #pragma unroll 2
@@ -248,17 +243,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     if (from_x) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) yv[j] = xv[j] * sc[j] + sh[j];
-    } else if (relu_mask) {
+    } else if (MODE == 3) {
       const unsigned m = relu_mask[i];
 #pragma unroll
       for (int j = 0; j < 8; ++j) yv[j] = ((m >> j) & 1u) ? 1.f : 0.f;
-    } else if (relu) unpack8(*reinterpret_cast<const u32x4*>(y + i * 8), yv);
+    } else if (MODE == 1) unpack8(*reinterpret_cast<const u32x4*>(y + i * 8), yv);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float dz = (relu && !(yv[j] > 0.f)) ? 0.f : g[j];
+      const float dz = (MODE != 0 && !(yv[j] > 0.f)) ? 0.f : g[j];
       g[j] = dz;
-      const float xh = (xv[j] - mu[j]) * rs[j];
-      o[j] = k1[j] * (dz - k2[j] - xh * k3[j]);
+      o[j] = kA[j] * dz + (kB[j] * xv[j] + kD[j]);
     }
     // streaming stores: the tensors are far larger than L2 / MALL and are not read again by this kernel
     __builtin_nontemporal_store(pack8(o), reinterpret_cast<u32x4*>(dx + i * 8));
@@ -274,35 +268,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 // Contributions are summed in the order of the materialising kernel and rounded to bf16 like its output.
 __device__ __forceinline__ void pooled_grad_2x2(const unsigned char* __restrict__ argmax, const unsigned short* __restrict__ gp,
                                                 const PoolGeom& g_, int n, int a, int b, int cg, float (&out)[4][8]) {
-  float acc[4][8];
-#pragma unroll
-  for (int p = 0; p < 4; ++p)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[p][j] = 0.f;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int jw = 0; jw < 2; ++jw) {
-      const int ho = a + i, wo = b + jw;
-      if (ho >= g_.Ho || wo >= g_.Wo) continue;
-      const int64_t o = (((int64_t)n * g_.Ho + ho) * g_.Wo + wo) * g_.C + cg * 8;
-      const u32x2 am = *reinterpret_cast<const u32x2*>(argmax + o);
-      float g[8];
-      unpack8(*reinterpret_cast<const u32x4*>(gp + o), g);
-#pragma unroll
-      for (int dy = i; dy < 2; ++dy)                    // window row i = 1 only reaches the lower pixels ...
-#pragma unroll
-        for (int dx = jw; dx < 2; ++dx) {               // ... window column 1 only the right ones
-          const unsigned code = (unsigned)((dy + 1 - 2 * i) * 3 + (dx + 1 - 2 * jw));
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const unsigned bsel = (am[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
-            if (bsel == code) acc[dy * 2 + dx][j] += g[j];
-          }
-        }
-    }
-#pragma unroll
-  for (int p = 0; p < 4; ++p) unpack8(pack8(acc[p]), out[p]);
+  isic_pool::Windows w;
+  isic_pool::load_windows(w, argmax, gp, g_, n, a, b, cg);
+  isic_pool::windows_to_grad(w, g_, a, b, out);
 }
 
 __global__ __launch_bounds__(256) void stem_bn_bwd_reduce_kernel(const unsigned char* __restrict__ argmax,
@@ -326,17 +294,22 @@ __global__ __launch_bounds__(256) void stem_bn_bwd_reduce_kernel(const unsigned 
     const int b = (int)(q % Wb);
     const int64_t t = q / Wb;
     const int a = (int)(t % Hb), n = (int)(t / Hb);
+    u32x4 xr[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {                       // clamped addresses: every load of the thread in flight at once
+      const int hi = min(2 * a + (p >> 1), geom.H - 1), wi = min(2 * b + (p & 1), geom.W - 1);
+      xr[p] = *reinterpret_cast<const u32x4*>(x + (((int64_t)n * geom.H + hi) * geom.W + wi) * C + cg * 8);
+    }
     float g[4][8];
     pooled_grad_2x2(argmax, gp, geom, n, a, b, cg, g);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int hi = 2 * a + (p >> 1), wi = 2 * b + (p & 1);
-      if (hi >= geom.H || wi >= geom.W) continue;
+      const bool in = (2 * a + (p >> 1) < geom.H) && (2 * b + (p & 1) < geom.W);
       float xv[8];
-      unpack8(*reinterpret_cast<const u32x4*>(x + (((int64_t)n * geom.H + hi) * geom.W + wi) * C + cg * 8), xv);
+      unpack8(xr[p], xv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float dz = (xv[j] * sc[j] + sh[j] > 0.f) ? g[p][j] : 0.f;
+        const float dz = (in && xv[j] * sc[j] + sh[j] > 0.f) ? g[p][j] : 0.f;
         acc[0][j] += dz * ((xv[j] - mu[j]) * rs[j]);
         acc[1][j] += dz;
       }
@@ -361,14 +334,13 @@ __global__ __launch_bounds__(256) void stem_bn_bwd_apply_kernel(
     }
   }
   const int cg = threadIdx.x % cgs;           // (the grid stride is a multiple of C/8)
-  float mu[8], rs[8], k1[8], k2[8], k3[8], sc[8], sh[8];
+  float kA[8], kB[8], kD[8], sc[8], sh[8];              // as in bn_bwd_apply_kernel
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = cg * 8 + j;
-    mu[j] = mean[c]; rs[j] = rstd[c];
-    k1[j] = gamma[c] * rs[j];
-    k2[j] = (float)dbeta[c] * inv_rows;
-    k3[j] = (float)dgamma[c] * inv_rows;
+    const float mu = mean[c], rs = rstd[c], k1 = gamma[c] * rs;
+    const float k2 = (float)dbeta[c] * inv_rows, k3 = (float)dgamma[c] * inv_rows;
+    kA[j] = k1; kB[j] = -k1 * k3 * rs; kD[j] = k1 * (k3 * rs * mu - k2);
     sc[j] = scale[c]; sh[j] = shift[c];
   }
   const int Hb = (geom.H + 1) >> 1, Wb = (geom.W + 1) >> 1;
@@ -378,6 +350,12 @@ __global__ __launch_bounds__(256) void stem_bn_bwd_apply_kernel(
     const int b = (int)(q % Wb);
     const int64_t t = q / Wb;
     const int a = (int)(t % Hb), n = (int)(t / Hb);
+    u32x4 xr[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {                       // clamped addresses: every load of the thread in flight at once
+      const int hi = min(2 * a + (p >> 1), geom.H - 1), wi = min(2 * b + (p & 1), geom.W - 1);
+      xr[p] = *reinterpret_cast<const u32x4*>(x + (((int64_t)n * geom.H + hi) * geom.W + wi) * C + cg * 8);
+    }
     float g[4][8];
     pooled_grad_2x2(argmax, gp, geom, n, a, b, cg, g);
 #pragma unroll
@@ -386,12 +364,11 @@ __global__ __launch_bounds__(256) void stem_bn_bwd_apply_kernel(
       if (hi >= geom.H || wi >= geom.W) continue;
       const int64_t off = (((int64_t)n * geom.H + hi) * geom.W + wi) * C + cg * 8;
       float xv[8], o[8];
-      unpack8(*reinterpret_cast<const u32x4*>(x + off), xv);
+      unpack8(xr[p], xv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float dz = (xv[j] * sc[j] + sh[j] > 0.f) ? g[p][j] : 0.f;
-        const float xh = (xv[j] - mu[j]) * rs[j];
-        o[j] = k1[j] * (dz - k2[j] - xh * k3[j]);
+        o[j] = kA[j] * dz + (kB[j] * xv[j] + kD[j]);
       }
       __builtin_nontemporal_store(pack8(o), reinterpret_cast<u32x4*>(dx + off));
     }
@@ -401,10 +378,12 @@ __global__ __launch_bounds__(256) void stem_bn_bwd_apply_kernel(
 // ---------------------------------------------------------------- pooling
 // scale != nullptr: the input is a raw convolution output and y = maxpool(relu(x * scale + shift)) -- the BatchNorm
 // apply and ReLU of the stem are done on the fly (each value rounded to bf16 as the materialised tensor would be)
+template <bool AFFINE>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const unsigned short* __restrict__ x,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            unsigned short* __restrict__ y,
-                                                           unsigned char* __restrict__ argmax, int N, int H, int W,
+                                                           unsigned char* __restrict__ argmax,
+                                                           unsigned short* __restrict__ xsel, int N, int H, int W,
                                                            int C, int Ho, int Wo) {
   const int cgs = C >> 3;
   const int64_t nvec = (int64_t)N * Ho * Wo * cgs;
@@ -414,40 +393,54 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const unsigned short* 
     const int wo = (int)(t % Wo); t /= Wo;
     const int ho = (int)(t % Ho);
     const int n = (int)(t / Ho);
-    float best[8], sc[8], sh[8];
+    // the nine taps at clamped (always valid) addresses: all loads are issued before the first one is used
+    u32x4 raw[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hi = min(max(ho * 2 - 1 + kh, 0), H - 1);
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int wi = min(max(wo * 2 - 1 + kw, 0), W - 1);
+        raw[kh * 3 + kw] = *reinterpret_cast<const u32x4*>(x + (((int64_t)n * H + hi) * W + wi) * C + cg * 8);
+      }
+    }
+    float best[8], bx[8], sc[8], sh[8];
     unsigned char bi[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; bi[j] = 0; }
-    if (scale) {
+    for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; bx[j] = 0.f; bi[j] = 0; }
+    if (AFFINE) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { sc[j] = scale[cg * 8 + j]; sh[j] = shift[cg * 8 + j]; }
     }
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       const int hi = ho * 2 - 1 + kh;
-      if (hi < 0 || hi >= H) continue;
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int wi = wo * 2 - 1 + kw;
-        if (wi < 0 || wi >= W) continue;
-        float f[8];
-        unpack8(*reinterpret_cast<const u32x4*>(x + (((int64_t)n * H + hi) * W + wi) * C + cg * 8), f);
-        if (scale) {
+        const bool in = hi >= 0 && hi < H && wi >= 0 && wi < W;
+        float f[8], r[8];
+        unpack8(raw[kh * 3 + kw], r);
+        if (AFFINE) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * sc[j] + sh[j], 0.f);
+          for (int j = 0; j < 8; ++j) f[j] = fmaxf(r[j] * sc[j] + sh[j], 0.f);
           unpack8(pack8(f), f);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = r[j];
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          if (f[j] > best[j]) { best[j] = f[j]; bi[j] = (unsigned char)(kh * 3 + kw); }  // first maximum wins
+          if (in && f[j] > best[j]) { best[j] = f[j]; bx[j] = r[j]; bi[j] = (unsigned char)(kh * 3 + kw); }  // first maximum wins
       }
     }
-    *reinterpret_cast<u32x4*>(y + i * 8) = pack8(best);
+    __builtin_nontemporal_store(pack8(best), reinterpret_cast<u32x4*>(y + i * 8));
+    if (xsel) __builtin_nontemporal_store(pack8(bx), reinterpret_cast<u32x4*>(xsel + i * 8));
     if (argmax) {
       u32x2 p;
       p[0] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | ((unsigned)bi[3] << 24);
       p[1] = bi[4] | (bi[5] << 8) | (bi[6] << 16) | ((unsigned)bi[7] << 24);
-      *reinterpret_cast<u32x2*>(argmax + i * 8) = p;
+      __builtin_nontemporal_store(p, reinterpret_cast<u32x2*>(argmax + i * 8));
     }
   }
 }
@@ -592,8 +585,11 @@ int isic_bn_bwd_reduce_bf16(const uint16_t* dy, const uint16_t* x, const uint16_
   ISIC_CHECK_ARG(!relu || y || scale);
   if (!bn_c_ok(C)) return ISIC_ERR_UNSUPPORTED;
   const int rls = 256 / (C / 8);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid_for(rows, rls * 8, 2048)), dim3(256), 0, as_stream(stream), dy, x,
-                     y, nullptr, mean, rstd, rows, C, relu, scale, shift, dgamma, dbeta);
+  const dim3 grid(grid_for(rows, rls * 8, 2048));
+#define ISIC_REDUCE(M) hipLaunchKernelGGL(bn_bwd_reduce_kernel<M>, grid, dim3(256), 0, as_stream(stream), dy, x, y, nullptr, \
+                                          mean, rstd, rows, C, relu, scale, shift, dgamma, dbeta)
+  if (!relu) ISIC_REDUCE(0); else if (scale) ISIC_REDUCE(2); else ISIC_REDUCE(1);
+#undef ISIC_REDUCE
   return isic_launch_status();
 }
 
@@ -602,7 +598,7 @@ int isic_bn_bwd_reduce_mask_bf16(const uint16_t* dy, const uint16_t* x, const ui
   ISIC_CHECK_ARG(dy && x && relu_mask && mean && rstd && dgamma && dbeta && rows > 0 && C > 0);
   if (!bn_c_ok(C)) return ISIC_ERR_UNSUPPORTED;
   const int rls = 256 / (C / 8);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid_for(rows, rls * 8, 2048)), dim3(256), 0, as_stream(stream), dy, x,
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel<3>, dim3(grid_for(rows, rls * 8, 2048)), dim3(256), 0, as_stream(stream), dy, x,
                      nullptr, relu_mask, mean, rstd, rows, C, 1, nullptr, nullptr, dgamma, dbeta);
   return isic_launch_status();
 }
@@ -630,8 +626,11 @@ int isic_bn_bwd_apply_bf16(const uint16_t* dy, const uint16_t* x, const uint16_t
   ISIC_CHECK_ARG((dgamma_f32 == nullptr) == (dbeta_f32 == nullptr));
   if (!bn_c_ok(C)) return ISIC_ERR_UNSUPPORTED;   // per-thread channel constants: C/8 must divide the 256-thread block
   const int64_t nvec = rows * (C / 8);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), dy, x, y, nullptr,
-                     mean, rstd, gamma, dgamma, dbeta, rows, C, relu, scale, shift, dx, d_residual, dgamma_f32, dbeta_f32);
+  const dim3 grid(grid_for(nvec, 256));
+#define ISIC_APPLY(M) hipLaunchKernelGGL(bn_bwd_apply_kernel<M>, grid, dim3(256), 0, as_stream(stream), dy, x, y, nullptr, mean, \
+                                         rstd, gamma, dgamma, dbeta, rows, C, relu, scale, shift, dx, d_residual, dgamma_f32, dbeta_f32)
+  if (!relu) ISIC_APPLY(0); else if (scale) ISIC_APPLY(2); else ISIC_APPLY(1);
+#undef ISIC_APPLY
   return isic_launch_status();
 }
 
@@ -643,7 +642,7 @@ int isic_bn_bwd_apply_mask_bf16(const uint16_t* dy, const uint16_t* x, const uin
   ISIC_CHECK_ARG((dgamma_f32 == nullptr) == (dbeta_f32 == nullptr));
   if (!bn_c_ok(C)) return ISIC_ERR_UNSUPPORTED;   // per-thread channel constants: C/8 must divide the 256-thread block
   const int64_t nvec = rows * (C / 8);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), dy, x, nullptr,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<3>, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), dy, x, nullptr,
                      relu_mask, mean, rstd, gamma, dgamma, dbeta, rows, C, 1, nullptr, nullptr, dx, d_residual, dgamma_f32,
                      dbeta_f32);
   return isic_launch_status();
@@ -669,18 +668,24 @@ int isic_maxpool3x3s2_fwd_bf16(const uint16_t* x, uint16_t* y, uint8_t* argmax, 
   ISIC_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0);
   ISIC_CHECK_ARG(Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1);
   const int64_t nvec = (int64_t)N * Ho * Wo * (C / 8);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), x, nullptr, nullptr,
-                     y, argmax, N, H, W, C, Ho, Wo);
+  hipLaunchKernelGGL(maxpool_fwd_kernel<false>, dim3(grid_for(nvec, 256, 16384)), dim3(256), 0, as_stream(stream), x, nullptr,
+                     nullptr, y, argmax, nullptr, N, H, W, C, Ho, Wo);
   return isic_launch_status();
 }
 
 int isic_bn_relu_maxpool3x3s2_fwd_bf16(const uint16_t* x, const float* scale, const float* shift, uint16_t* y,
                                        uint8_t* argmax, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
+  return isic_bn_relu_maxpool3x3s2_fwd_sel_bf16(x, scale, shift, y, argmax, nullptr, N, H, W, C, Ho, Wo, stream);
+}
+
+int isic_bn_relu_maxpool3x3s2_fwd_sel_bf16(const uint16_t* x, const float* scale, const float* shift, uint16_t* y,
+                                           uint8_t* argmax, uint16_t* x_sel, int N, int H, int W, int C, int Ho, int Wo,
+                                           void* stream) {
   ISIC_CHECK_ARG(x && scale && shift && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0);
   ISIC_CHECK_ARG(Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1);
   const int64_t nvec = (int64_t)N * Ho * Wo * (C / 8);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, as_stream(stream), x, scale, shift, y,
-                     argmax, N, H, W, C, Ho, Wo);
+  hipLaunchKernelGGL(maxpool_fwd_kernel<true>, dim3(grid_for(nvec, 256, 16384)), dim3(256), 0, as_stream(stream), x, scale,
+                     shift, y, argmax, x_sel, N, H, W, C, Ho, Wo);
   return isic_launch_status();
 }
 

@@ -376,8 +376,9 @@ class ResNet18Encoder(nn.Module):
         Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
         p = _empty((N, Hp, Wp, 64), c)
         am = torch.empty((N, Hp, Wp, 64), device=c.device, dtype=torch.uint8) if save else None
-        call("isic_bn_relu_maxpool3x3s2_fwd_bf16", c, st0[2], st0[3], p, am, N, Ho, Wo, 64, Hp, Wp)
-        tape = {"x0": x0, "stem": (c, st0, am, (N, Ho, Wo, 64)), "blocks": []} if save else None
+        csel = _empty((N, Hp, Wp, 64), c) if save else None    # raw stem output at each window's argmax (bn1 backward sums)
+        call("isic_bn_relu_maxpool3x3s2_fwd_sel_bf16", c, st0[2], st0[3], p, am, csel, N, Ho, Wo, 64, Hp, Wp)
+        tape = {"x0": x0, "stem": (c, st0, am, csel, (N, Ho, Wo, 64)), "blocks": []} if save else None
         x = p
         for pre, ds in self.blocks:
             x, saved = self.block_forward(x, pre, ds)
@@ -434,25 +435,25 @@ class ResNet18Encoder(nn.Module):
         for (pre, ds), saved in zip(reversed(self.blocks), reversed(tape["blocks"])):
             g, names = self.block_backward(g, pre, ds, saved)
             self._fire(names)
-        c, st0, am, yshape = tape["stem"]
+        c, st0, am, csel, yshape = tape["stem"]
         N, Ho, Wo, _ = yshape
         _, Hp, Wp, _ = g.shape
-        # max-pool backward gathered inside the BatchNorm backward passes: no full-size gradient tensor
+        # bn1 backward without a full-size gradient tensor.  Sums: a pooling window's gradient reaches exactly its
+        # argmax pixel, so they are a pass over the POOLED tensors (g, the raw activation at the argmax).  Apply: fused
+        # into the stem weight gradient, which forms dY = bn_bwd(maxpool_bwd(g)) in registers from c, g and argmax.
         mean, rstd, scale, shift = st0
         gamma, beta = self._get("bn1.weight"), self._get("bn1.bias")
         acc = self._zeros64((2, 64), c.device)
-        call("isic_bn_bwd_reduce_pooled_bf16", am, g, c, mean, rstd, N, Ho, Wo, 64, Hp, Wp, scale, shift, acc[0], acc[1])
-        dc = _empty(c.shape, c)
-        call("isic_bn_bwd_apply_pooled_bf16", am, g, c, mean, rstd, gamma.data, acc[0], acc[1], N, Ho, Wo, 64, Hp, Wp,
-             scale, shift, dc, self._grad_buffer(gamma), self._grad_buffer(beta))
+        call("isic_bn_bwd_reduce_bf16", g, csel, None, mean, rstd, N * Hp * Wp, 64, 1, scale, shift, acc[0], acc[1])
         x0 = tape["x0"]
         p = self._get("conv1.weight")
-        gw = self._grad_buffer(p)
-        self._on_side(dc.device, (x0, dc),
-                      lambda: call("isic_conv_stem_wgrad_bf16", x0, dc, gw, N, x0.shape[1], x0.shape[2], Ho, Wo))
+        gw, gg, gb = self._grad_buffer(p), self._grad_buffer(gamma), self._grad_buffer(beta)
+        self._on_side(c.device, (x0, c, g, am, acc),
+                      lambda: call("isic_conv_stem_wgrad_bn_pooled_bf16", x0, c, am, g, mean, rstd, gamma.data, scale, shift,
+                                   acc[0], acc[1], gw, gg, gb, N, x0.shape[1], x0.shape[2], Ho, Wo, Hp, Wp))
         self._fire(["conv1.weight", "bn1.weight", "bn1.bias"])
         if self._side is not None:
-            torch.cuda.current_stream(dc.device).wait_stream(self._side)   # gradients complete for whoever comes next
+            torch.cuda.current_stream(c.device).wait_stream(self._side)    # gradients complete for whoever comes next
 
     def forward(self, images):
         if torch.is_grad_enabled() and self.training:

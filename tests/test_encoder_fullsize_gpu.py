@@ -183,7 +183,7 @@ def test_configs1_full_size_forward_backward(images):
         r = (v + 1e-5).rsqrt()
         assert float(((rstd.double() - r).abs() / r).max()) <= 1e-4, name
 
-    c, st0, am, _ = tape["stem"]
+    c, st0, am, _, _ = tape["stem"]
     x0 = tape["x0"]                                      # NHWC4 bf16
     ws, _ = enc._weights("conv1", False)
     check_bn(c, st0, "bn1")

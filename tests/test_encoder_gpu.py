@@ -345,6 +345,83 @@ def test_stem_fused_bn_relu_maxpool_and_pooled_bn_backward(shape):
     assert torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
 
 
+@pytest.mark.parametrize("shape", [(2, 12, 12), (3, 9, 13), (2, 112, 112)])
+def test_stem_argmax_selection_and_sparse_bn_reduce(shape):
+    """x_sel of the fused pool = raw input at each window's argmax; the BatchNorm backward sums taken over the POOLED
+    tensors (gradient, x_sel) equal the sums over the full-size tensor (a window's gradient reaches only its argmax)."""
+    from isic_hip.lib import call
+    N, H, W = shape
+    C = 64
+    g = torch.Generator().manual_seed(37)
+    x = torch.randn(N, H, W, C, generator=g).to(DEV).to(BF)
+    scale = (torch.rand(C, generator=g) + 0.5).to(DEV) * torch.where(torch.arange(C) % 5 == 0, -1.0, 1.0).to(DEV)
+    shift = (torch.randn(C, generator=g) * 0.3).to(DEV)
+    mean = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    rstd = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    p0, am0 = torch.empty(N, Ho, Wo, C, device=DEV, dtype=BF), torch.empty(N, Ho, Wo, C, device=DEV, dtype=torch.uint8)
+    call("isic_bn_relu_maxpool3x3s2_fwd_bf16", x, scale, shift, p0, am0, N, H, W, C, Ho, Wo)
+    p, am, xs = torch.empty_like(p0), torch.empty_like(am0), torch.empty_like(p0)
+    call("isic_bn_relu_maxpool3x3s2_fwd_sel_bf16", x, scale, shift, p, am, xs, N, H, W, C, Ho, Wo)
+    assert torch.equal(p.view(torch.int16), p0.view(torch.int16)) and torch.equal(am, am0)
+    # gather reference on the host
+    xc, amc = x.float().cpu(), am.cpu().long()
+    ho = torch.arange(Ho).view(1, Ho, 1, 1)
+    wo = torch.arange(Wo).view(1, 1, Wo, 1)
+    hi, wi = ho * 2 - 1 + amc // 3, wo * 2 - 1 + amc % 3
+    assert int(hi.min()) >= 0 and int(hi.max()) < H and int(wi.min()) >= 0 and int(wi.max()) < W
+    n_i = torch.arange(N).view(N, 1, 1, 1).expand_as(amc)
+    c_i = torch.arange(C).view(1, 1, 1, C).expand_as(amc)
+    assert torch.equal(xs.float().cpu(), xc[n_i, hi.expand_as(amc), wi.expand_as(amc), c_i])
+    gp = torch.randn(N, Ho, Wo, C, generator=g).to(DEV).to(BF)
+    ref = torch.zeros(2, C, device=DEV, dtype=torch.float64)
+    call("isic_bn_bwd_reduce_pooled_bf16", am, gp, x, mean, rstd, N, H, W, C, Ho, Wo, scale, shift, ref[0], ref[1])
+    acc = torch.zeros(2, C, device=DEV, dtype=torch.float64)
+    call("isic_bn_bwd_reduce_bf16", gp, xs, None, mean, rstd, N * Ho * Wo, C, 1, scale, shift, acc[0], acc[1])
+    # the full-size form rounds each pixel's summed gradient to bf16 first (<= 4 windows per pixel): 2^-9 per term
+    tol = 2.0 ** -8 * float((gp.float().abs().sum() / C).cpu()) * float(rstd.max()) * 0.05
+    assert_close(acc.cpu(), ref.cpu(), rtol=2e-3, atol=max(tol, 1e-3), what="sparse bn reduce")
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32), (3, 20, 44), (2, 224, 224)])
+def test_stem_wgrad_from_pooled_gradient(shape):
+    """The weight gradient that forms dY in registers (max-pool backward -> BatchNorm backward) equals
+    isic_bn_bwd_apply_pooled_bf16 followed by isic_conv_stem_wgrad_bf16 on the materialised dY."""
+    from isic_hip.lib import call
+    N, H, W = shape
+    C = 64
+    g = torch.Generator().manual_seed(41)
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
+    x4 = torch.zeros(N, H, W, 4)
+    x4[..., :3] = torch.randn(N, H, W, 3, generator=g)
+    x4 = x4.to(DEV).to(BF)
+    y0 = torch.randn(N, Ho, Wo, C, generator=g).to(DEV).to(BF)
+    scale = (torch.rand(C, generator=g) + 0.5).to(DEV) * torch.where(torch.arange(C) % 5 == 0, -1.0, 1.0).to(DEV)
+    shift = (torch.randn(C, generator=g) * 0.3).to(DEV)
+    mean = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    rstd = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    p, am = torch.empty(N, Hp, Wp, C, device=DEV, dtype=BF), torch.empty(N, Hp, Wp, C, device=DEV, dtype=torch.uint8)
+    call("isic_bn_relu_maxpool3x3s2_fwd_bf16", y0, scale, shift, p, am, N, Ho, Wo, C, Hp, Wp)
+    gp = torch.randn(N, Hp, Wp, C, generator=g).to(DEV).to(BF)
+    acc = torch.zeros(2, C, device=DEV, dtype=torch.float64)
+    call("isic_bn_bwd_reduce_pooled_bf16", am, gp, y0, mean, rstd, N, Ho, Wo, C, Hp, Wp, scale, shift, acc[0], acc[1])
+    dy = torch.empty_like(y0)
+    dg_ref, db_ref = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    call("isic_bn_bwd_apply_pooled_bf16", am, gp, y0, mean, rstd, gamma, acc[0], acc[1], N, Ho, Wo, C, Hp, Wp, scale, shift,
+         dy, dg_ref, db_ref)
+    dw_ref = torch.zeros(64, 3, 7, 7, device=DEV).contiguous(memory_format=torch.channels_last)
+    call("isic_conv_stem_wgrad_bf16", x4, dy, dw_ref, N, H, W, Ho, Wo)
+    dw = torch.zeros_like(dw_ref)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    call("isic_conv_stem_wgrad_bn_pooled_bf16", x4, y0, am, gp, mean, rstd, gamma, scale, shift, acc[0], acc[1], dw, dg, db,
+         N, H, W, Ho, Wo, Hp, Wp)
+    assert torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+    # identical bf16 operands and tiles; only the order of the fp32 atomics differs
+    assert_close(dw.cpu(), dw_ref.cpu(), rtol=1e-4, atol=1e-4 * float(dw_ref.abs().max().cpu()), what="fused stem wgrad")
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 32), (3, 20, 44), (1, 224, 224)])
 def test_stem_forward_and_wgrad(shape):
     from isic_hip.lib import call

@@ -1,0 +1,67 @@
+"""Micro-benchmark of the stem's HBM-bound passes at the BASELINE.json configs[1] step shape (N images of 224x224):
+fused BatchNorm+ReLU+max-pool forward, BatchNorm backward sums (full-size vs pooled-only), and the stem weight
+gradient fed by the materialised dY vs by the pooled gradient.  Developer tool:  python tools/stem_bench.py [--n 2048]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "multimodal-isic_amd"))
+import torch
+from isic_hip.lib import call
+
+BF, DEV = torch.bfloat16, "cuda:0"
+
+
+def timeit(fn, iters=5):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=2048)
+    N = ap.parse_args().n
+    C, H, W, Ho, Wo, Hp, Wp = 64, 224, 224, 112, 112, 56, 56
+    x4 = torch.randn(N, H, W, 4, device=DEV).to(BF)
+    y0 = torch.randn(N, Ho, Wo, C, device=DEV).to(BF)
+    scale, shift = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.3
+    mean, rstd, gamma = torch.randn(C, device=DEV) * 0.1, torch.rand(C, device=DEV) + 0.5, torch.rand(C, device=DEV) + 0.5
+    p, xs = torch.empty(N, Hp, Wp, C, device=DEV, dtype=BF), torch.empty(N, Hp, Wp, C, device=DEV, dtype=BF)
+    am = torch.empty(N, Hp, Wp, C, device=DEV, dtype=torch.uint8)
+    gp = torch.randn(N, Hp, Wp, C, device=DEV).to(BF)
+    acc = torch.zeros(2, C, device=DEV, dtype=torch.float64)
+    dy = torch.empty_like(y0)
+    dw = torch.zeros(64, 3, 7, 7, device=DEV).contiguous(memory_format=torch.channels_last)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    gb_full, gb_pool = y0.numel() * 2 / 1e9, p.numel() * 2 / 1e9
+    rows = [
+        ("bn+relu+maxpool fwd (+argmax, +x_sel)", gb_full + 2.5 * gb_pool,
+         lambda: call("isic_bn_relu_maxpool3x3s2_fwd_sel_bf16", y0, scale, shift, p, am, xs, N, Ho, Wo, C, Hp, Wp)),
+        ("bn bwd sums, full-size (old)", gb_full + 1.5 * gb_pool,
+         lambda: call("isic_bn_bwd_reduce_pooled_bf16", am, gp, y0, mean, rstd, N, Ho, Wo, C, Hp, Wp, scale, shift, acc[0], acc[1])),
+        ("bn bwd sums, pooled only (new)", 2 * gb_pool,
+         lambda: call("isic_bn_bwd_reduce_bf16", gp, xs, None, mean, rstd, N * Hp * Wp, C, 1, scale, shift, acc[0], acc[1])),
+        ("bn bwd apply -> dY (old)", 2 * gb_full + 1.5 * gb_pool,
+         lambda: call("isic_bn_bwd_apply_pooled_bf16", am, gp, y0, mean, rstd, gamma, acc[0], acc[1], N, Ho, Wo, C, Hp, Wp,
+                      scale, shift, dy, dg, db)),
+        ("stem wgrad from dY (old)", gb_full + x4.numel() * 2 / 1e9,
+         lambda: call("isic_conv_stem_wgrad_bf16", x4, dy, dw, N, H, W, Ho, Wo)),
+        ("stem wgrad from pooled gradient (new)", gb_full + 1.5 * gb_pool + x4.numel() * 2 / 1e9,
+         lambda: call("isic_conv_stem_wgrad_bn_pooled_bf16", x4, y0, am, gp, mean, rstd, gamma, scale, shift, acc[0], acc[1],
+                      dw, dg, db, N, H, W, Ho, Wo, Hp, Wp)),
+    ]
+    for name, gb, fn in rows:
+        t = timeit(fn)
+        print(f"{name:44s} {t:7.3f} ms  {gb:6.2f} GB compulsory  {gb / t:5.2f} TB/s")
+
+
+if __name__ == "__main__":
+    main()
