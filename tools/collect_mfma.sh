@@ -14,8 +14,10 @@ python3 - <<PY
 import csv, glob, json, collections
 f = glob.glob("$R/gpurun_out/mfma/pmc/*/*counter_collection.csv")[0]
 def group(k):
-    if "conv_igemm" in k: return "conv_igemm (>=128-channel and strided forward / data gradient)"
-    if "conv3x3_c64" in k or "conv_halo" in k: return "conv3x3_c64p (64->64 forward / data gradient)"
+    if "conv_halo" in k: return "conv_halo (3x3 stride-1 forward / data gradient, >=128 channels)"
+    if "conv_pgemm" in k: return "conv_pgemm (stride-2 3x3 and 1x1 forward, stride-2 data gradients with >=128 outputs)"
+    if "conv_igemm" in k: return "conv_igemm (generic: data gradients with 64 outputs, 1x1 data gradients)"
+    if "conv3x3_c64" in k: return "conv3x3_c64p (64->64 forward / data gradient)"
     if "wgrad_c64_kernel" in k: return "wgrad_c64 (64->64 weight gradient)"
     if "wgrad_c128_kernel" in k: return "wgrad_c128 (128->128 weight gradient)"
     if "conv_wgrad_kernel" in k: return "conv_wgrad (other weight gradients)"

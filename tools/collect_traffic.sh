@@ -27,7 +27,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if "adam_step_kernel" in k:
             adam.add(r["Dispatch_Id"])
         # isic_conv2d_igemm_bf16 dispatches the generic implicit GEMM or the halo-resident 3x3 kernels
-        name = ("conv_igemm" if ("conv_igemm" in k or "conv3x3_c64" in k or "conv_halo" in k) else
+        name = ("conv_igemm" if ("conv_igemm" in k or "conv3x3_c64" in k or "conv_halo" in k or "conv_pgemm" in k) else
                 "conv_wgrad" if ("wgrad" in k and "table" not in k and "reduce" not in k) else None)
         if name and r["Counter_Name"] == c:
             agg[name][0] += float(r["Counter_Value"]); agg[name][1].add(r["Dispatch_Id"])
