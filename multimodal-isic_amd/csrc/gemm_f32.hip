@@ -160,6 +160,43 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
   }
 }
 
+// Column sums of a tall matrix (bias gradients over all the nodes of a batch: M ~ 50 k rows, N = 128..512): 16-byte
+// loads (a thread owns 4 consecutive columns), VGB vector groups x 1024/VGB row lanes per block, four rows in flight per
+// thread; LDS tree over the row lanes, one atomic per column and block into the pre-scaled output.  FEW, FAT blocks:
+// same-address atomics retire at ~3 ns each per cache line (measured: 392 blocks x 128 columns took 41 us, all of it
+// atomics), so the grid is ~96 blocks of 16 waves, not one block per 128 rows.
+template <int VGB>
+__global__ __launch_bounds__(1024) void colsum4_kernel(const float* __restrict__ X, int M, int N, int ldx,
+                                                       float* __restrict__ out, int rows_per_block) {
+  constexpr int RL = 1024 / VGB;
+  __shared__ f32x4 part[1024];
+  const int vg = threadIdx.x % VGB, rl = threadIdx.x / VGB;
+  const int col = (blockIdx.x * VGB + vg) * 4;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  if (col < N) {
+    const float* p = X + col;
+    int r = r0 + rl;
+    for (; r + 3 * RL < r1; r += 4 * RL) {
+      const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (size_t)r * ldx));
+      const f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (size_t)(r + RL) * ldx));
+      const f32x4 c = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (size_t)(r + 2 * RL) * ldx));
+      const f32x4 d = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (size_t)(r + 3 * RL) * ldx));
+      s0 += a; s1 += b; s2 += c; s3 += d;
+    }
+    for (; r < r1; r += RL) s0 += *reinterpret_cast<const f32x4*>(p + (size_t)r * ldx);
+  }
+  part[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rl == 0 && col < N) {
+    f32x4 t = part[vg];
+#pragma unroll
+    for (int k = 1; k < RL; ++k) t += part[k * VGB + vg];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(out + col + e, t[e]);
+  }
+}
+
 __global__ void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ t, float* __restrict__ dx,
                                 int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -250,6 +287,23 @@ int isic_colsum_f32(const float* X, int M, int N, int ldx, float* out, float bet
   ISIC_CHECK_ARG(M >= 0 && N >= 0 && ldx >= N);
   if (N == 0) return ISIC_OK;
   ISIC_CHECK_ARG(X && out);
+  if (M >= 8192 && N % 4 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+    const int nv = N / 4;
+    const int vgb = nv >= 64 ? 64 : nv > 16 ? 32 : 16;
+    const int colblocks4 = ceil_div(nv, vgb);
+    int chunks4 = ceil_div(96, colblocks4);                        // few fat blocks: see colsum4_kernel
+    const int min_rows = 4 * (1024 / vgb) * 2;                     // at least two unrolled iterations per thread
+    if (chunks4 > M / min_rows) chunks4 = M / min_rows;
+    if (chunks4 < 1) chunks4 = 1;
+    const int rpb = ceil_div(M, chunks4);
+    chunks4 = ceil_div(M, rpb);
+    hipLaunchKernelGGL(gemm_scale_kernel, dim3(1), dim3(256), 0, as_stream(stream), out, 1, N, N, beta);
+    const dim3 grid(colblocks4, chunks4);
+    if (vgb == 64) hipLaunchKernelGGL(colsum4_kernel<64>, grid, dim3(1024), 0, as_stream(stream), X, M, N, ldx, out, rpb);
+    else if (vgb == 32) hipLaunchKernelGGL(colsum4_kernel<32>, grid, dim3(1024), 0, as_stream(stream), X, M, N, ldx, out, rpb);
+    else hipLaunchKernelGGL(colsum4_kernel<16>, grid, dim3(1024), 0, as_stream(stream), X, M, N, ldx, out, rpb);
+    return isic_launch_status();
+  }
   // few column blocks x many rows (bias gradients over all the nodes of a batch): split the rows over blockIdx.y
   int chunks = 1;
   const int colblocks = ceil_div(N, 64);
