@@ -84,6 +84,7 @@ class ResNet18Encoder(nn.Module):
         self._zeros = None            # fp64 arena for the per-layer statistics accumulators: ONE memset per pass
         self._zeros_used = 0
         self._side = None             # second HIP stream: weight gradients run beside the data-gradient chain
+        self.wgrad_stream = False     # opt-in (attribute, not an environment switch): see _side_stream
         self.grad_ready_hook = None   # callable(list_of_param_names) fired as gradients complete (DDP overlap)
 
     # parameters are registered under dotted torchvision names via nested holder modules
@@ -194,12 +195,12 @@ class ResNet18Encoder(nn.Module):
         return v
 
     def _side_stream(self, device):
-        """Weight gradients are leaves of the backward graph: with ISIC_WGRAD_STREAM=1 they run on a second
+        """Weight gradients are leaves of the backward graph: with ``self.wgrad_stream = True`` they run on a second
         stream, so that the MFMA-bound wgrad kernels overlap the HBM-bound BatchNorm passes of the
         data-gradient chain and fill the partial last round of its convolution grids (+2 % bags/s on one
         MI355X).  Off by default: concurrent kernels stretch each other, which blurs per-kernel timings
         (bench.py's roofline, rocprofv3 summaries)."""
-        if os.environ.get("ISIC_WGRAD_STREAM", "0") != "1":
+        if not self.wgrad_stream:
             return None
         if self._side is None or self._side.device != device:
             self._side = torch.cuda.Stream(device=device)
