@@ -385,6 +385,27 @@ int isic_avgpool_bwd_bf16(const float* dy, uint16_t* dx, int N, int HW, int C, v
 /* a += b on bf16 tensors (gradient join of a residual block); n % 8 == 0. */
 int isic_add_bf16(uint16_t* a, const uint16_t* b, int64_t n, void* stream);
 
+/* ---------------------------------------------------------------- ViT-S/16 patch encoder, fp16 (BASELINE.json configs[4])
+ * The reference's frozen encoder is an un-vendored ConvMAE conv-ViT (save_latent.py:42-60: eval(), no_grad,
+ * forward(images, mask_ratio=0) -> latent[B,196,768]); these are the forward pieces of the ViT-S/16 this build puts in
+ * its place (timm layout: pre-norm blocks, no class token here).  fp16 tensors travel as uint16_t bit patterns.
+ *
+ * C[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ residual): nn.Linear with its epilogue fused.  act: 0 none, 1 erf-GELU
+ * (no residual with it).  residual_rows == 0: residual[M,N]; > 0: residual[residual_rows,N] broadcast over
+ * m % residual_rows (the position embedding of the patch projection).  K % 64 == 0, N % 128 == 0, else UNSUPPORTED. */
+int isic_gemm_f16(const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* residual, uint16_t* C,
+                  int M, int N, int K, int act, int residual_rows, void* stream);
+/* images NCHW fp32 -> rows[N*(H/P)*(W/P)][C*P*P] fp16: the im2col of the P x P / stride P patch projection
+ * (Conv2d weight [D][C][P][P] flattened is the Linear weight).  P % 8 == 0, H % P == W % P == 0. */
+int isic_vit_patchify_f16(const float* images_nchw, uint16_t* rows, int N, int C, int H, int W, int P, void* stream);
+/* LayerNorm over rows of N in {128, 256, 384, 512} fp16 values, fp32 arithmetic; writes y (fp16) and / or y_f32. */
+int isic_layernorm_f16(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* y_f32, int64_t M,
+                       int N, float eps, void* stream);
+/* Multi-head self-attention over the tokens of one image: qkv[n_images*tokens][3*heads*64] (q | k | v, head-major
+ * inside each) -> out[n_images*tokens][heads*64] = softmax(q k^T / 8) v per (image, head).  head_dim 64, tokens <= 208. */
+int isic_attention_f16(const uint16_t* qkv, uint16_t* out, int n_images, int tokens, int heads, int head_dim,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

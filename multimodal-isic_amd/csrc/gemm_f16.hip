@@ -1,0 +1,253 @@
+// Persistent fp16 GEMM on MFMA (gfx950) for the ViT-S/16 patch encoder of BASELINE.json configs[4]:
+//   C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) (+ residual),   fp16 in / out, fp32 accumulate
+// i.e. nn.Linear with the bias, the GELU of the MLP and the residual add of a transformer block (or the broadcast
+// position embedding of the patch projection) fused into the epilogue.  M = images x 196 tokens (0.4 M rows at 2048
+// images), K, N in {384, 768, 1152, 1536}: K % 64 == 0, N % 128 == 0.
+//
+// Same machine as conv_pgemm.hip without the convolution addressing: 1024 threads, waves 0-7 multiply (4 x 2 waves of
+// 64 x 64 = 4 x 4 v_mfma_f32_16x16x32_f16 tiles, operand roles swapped so that a lane ends with consecutive output
+// columns of one row), waves 8-15 only issue LDS-DMA (four 1 KB pieces of A rows and two of W rows per K-tile of 64,
+// 16-byte chunks XOR-swizzled on the source side), three 48 KB stages, one s_barrier per K-tile, counted vmcnt.  A block
+// is persistent over a contiguous range of 256-row tiles of one 128-column slice (W stays hot in L2, the staging
+// waves run two K-tiles ahead across tile boundaries) and the epilogue is register-only: the W rows are permuted inside
+// a stage so that a lane owns eight consecutive columns -> one 16-byte residual load and one 16-byte store per 8 values.
+//
+// The reference's encoder is an un-vendored ConvMAE conv-ViT run frozen under no_grad (save_latent.py:42-60); this is
+// this build's definition of the ViT-S/16 named by BASELINE.json (oracle/vit.py restates it on the CPU in fp32).
+#include <mutex>
+
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int GM = 256, GN = 128;
+constexpr int G_A = GM * 128, G_B = GN * 128, G_STAGE = G_A + G_B;   // bytes per K-tile
+constexpr int G_NST = 3;
+constexpr int G_PER_IT = 6;                 // DMAs per staging wave and K-tile
+constexpr int G_LDS = G_NST * G_STAGE + 1024 + 512;                  // ring | DMA scratch | the slice's 128 biases
+
+struct GemmF16Args {
+  const unsigned short* A;      // [M][K]
+  const unsigned short* W;      // [N][K]
+  const float* bias;            // [N] or null
+  const unsigned short* res;    // [M][N] (res_rows == 0) or [res_rows][N] broadcast over m % res_rows, or null
+  unsigned short* C;            // [M][N]
+  int M, N, K, Ktiles, act, res_rows, mtiles, tiles_per_block;
+};
+
+__device__ __attribute__((aligned(256))) unsigned char g_g16_zero_page[256];
+
+__device__ __forceinline__ void g16_glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned g16_pack2(float lo, float hi) {
+  const f16x2 h = {(_Float16)lo, (_Float16)hi};                     // round to nearest even
+  return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ float g16_lo(unsigned w) { return (float)__builtin_bit_cast(f16x2, w)[0]; }
+__device__ __forceinline__ float g16_hi(unsigned w) { return (float)__builtin_bit_cast(f16x2, w)[1]; }
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+
+template <bool GELU, bool RES>
+__global__ __launch_bounds__(1024) void gemm_f16_kernel(GemmF16Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  constexpr int off_scr = G_NST * G_STAGE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = blockIdx.y * GN;
+  const int t_begin = blockIdx.x * a.tiles_per_block;
+  const int ntl = min(a.mtiles - t_begin, a.tiles_per_block);
+  if (ntl <= 0) return;                                    // whole block: no barrier has been reached yet
+  const int KT = a.Ktiles;
+  const int total_it = ntl * KT;
+
+  if (wave >= 8) {
+    // =================================================================== staging waves
+    const int sw = wave - 8;
+    const int r8 = lane >> 3;
+    const int gch = (lane & 7) ^ r8;                       // global 16-byte chunk this lane fetches (swizzle on the source)
+    const unsigned char* zp = g_g16_zero_page + (lane & 7) * 16;
+    const unsigned scr = lds0 + off_scr;
+    // W: stage rows sr = 16*sw + 8*t + r8 (t = 0, 1) hold output column
+    //   wn*64 + 32*(j>>1) + 8*(rho>>2) + 4*(j&1) + (rho&3)   with wn = sr>>6, j = (sr>>4)&3, rho = sr&15
+    // so that a lane's results of MFMA tiles 2t', 2t'+1 are EIGHT CONSECUTIVE columns (conv_halo.hip)
+    const int chan0 = (sw >> 2) * 64 + ((sw & 3) >> 1) * 32 + (r8 >> 2) * 8 + (sw & 1) * 4 + (r8 & 3);   // t = 0; t = 1: + 16
+    const unsigned short* wrow = a.W + (size_t)(n0 + chan0) * a.K + gch * 8;
+
+    const unsigned short* a_ptr[4];
+    bool a_ok[4];
+    auto tile_rows = [&](int tl) {
+      const int m0 = (t_begin + tl) * GM;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 8 * (sw + 8 * i) + r8;
+        a_ok[i] = m < a.M;
+        a_ptr[i] = a.A + (size_t)(a_ok[i] ? m : 0) * a.K + gch * 8;
+      }
+    };
+    auto issue = [&](int kt, int stage, bool live) {
+      const unsigned sbase = lds0 + stage * G_STAGE;
+      const int koff = kt * 64;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const void* src = (live && a_ok[i]) ? (const void*)(a_ptr[i] + koff) : (const void*)zp;
+        g16_glds16(src, live ? sbase + (unsigned)((sw + 8 * i) * 1024) : scr);
+      }
+      g16_glds16(live ? (const void*)(wrow + koff) : (const void*)zp, live ? sbase + G_A + sw * 2048 : scr);
+      g16_glds16(live ? (const void*)(wrow + koff + (size_t)16 * a.K) : (const void*)zp, live ? sbase + G_A + sw * 2048 + 1024 : scr);
+    };
+    int itile = 0, ikt = 0;
+    tile_rows(0);
+    auto advance = [&]() {
+      if (++ikt == KT) { ikt = 0; ++itile; if (itile < ntl) tile_rows(itile); }
+    };
+    issue(0, 0, true); advance();
+    issue(ikt, 1, total_it > 1); advance();
+    for (int it = 0; it < total_it; ++it) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G_PER_IT) : "memory");     // K-tile `it` has landed
+      __builtin_amdgcn_s_barrier();
+      issue(ikt, (it + 2) % G_NST, it + 2 < total_it);
+      advance();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA may outlive the block's LDS allocation
+  } else {
+    // ===================================================================== MFMA waves
+    const int fr = lane & 15, fg = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const unsigned aoff0 = (unsigned)((wm * 64 + fr) * 128 + ((fg ^ (fr & 7)) << 4));
+    const unsigned boff0 = (unsigned)(G_A + (wn * 64 + fr) * 128 + ((fg ^ (fr & 7)) << 4));
+    const unsigned chan = (unsigned)(n0 + wn * 64 + fg * 8);
+    // the slice's biases in LDS (read back per 4 columns in the epilogue: no registers held across the K loop)
+    float* bias_lds = reinterpret_cast<float*>(smem + off_scr + 1024);
+    if (tid < GN) bias_lds[tid] = a.bias ? a.bias[n0 + tid] : 0.f;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // visible after the first K-tile barrier
+
+    int it = 0;
+    for (int tl = 0; tl < ntl; ++tl) {
+      const int m0 = (t_begin + tl) * GM;
+      f32x4 acc[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+      for (int kt = 0; kt < KT; ++kt, ++it) {
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* st = smem + (it % G_NST) * G_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          f16x8 af[4], bfr[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            af[i] = *reinterpret_cast<const f16x8*>(st + ((aoff0 ^ (unsigned)(ks << 6)) + i * 2048));
+            bfr[i] = *reinterpret_cast<const f16x8*>(st + ((boff0 ^ (unsigned)(ks << 6)) + i * 2048));
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+      }
+
+      // ---- register-only epilogue: lane (fg, fr) holds, for MFMA tiles (i, 2t) and (i, 2t+1), the eight consecutive
+      //      columns n0 + wn*64 + 32t + 8fg + {0..7} of row m0 + wm*64 + i*16 + fr
+      size_t off[4];
+      bool valid[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + fr;
+        valid[i] = m < a.M;
+        off[i] = (size_t)(valid[i] ? m : 0) * a.N + chan;
+      }
+      u32x4 rs[4][2];
+      if (RES) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = m0 + wm * 64 + i * 16 + fr;
+          const size_t roff = a.res_rows > 0 ? (size_t)((valid[i] ? m : 0) % a.res_rows) * a.N + chan : off[i];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) rs[i][t] = *reinterpret_cast<const u32x4*>(a.res + roff + t * 32);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          u32x4 v;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            f32x4 c = acc[i][2 * t + h] + *reinterpret_cast<const f32x4*>(bias_lds + wn * 64 + fg * 8 + t * 32 + 4 * h);
+            if (GELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) c[e] = gelu_erf(c[e]);
+            }
+            if (RES) {
+              const unsigned lo = rs[i][t][2 * h], hi = rs[i][t][2 * h + 1];
+              c[0] += g16_lo(lo); c[1] += g16_hi(lo); c[2] += g16_lo(hi); c[3] += g16_hi(hi);
+            }
+            v[2 * h] = g16_pack2(c[0], c[1]);
+            v[2 * h + 1] = g16_pack2(c[2], c[3]);
+          }
+          if (valid[i]) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.C + off[i] + t * 32));
+        }
+    }
+  }   // MFMA waves
+}
+
+template <bool GELU, bool RES>
+int launch_g16(const GemmF16Args& a, dim3 grid, hipStream_t stream) {
+  static std::once_flag once;
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(once, [] {
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<GELU, RES>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
+  });
+  if (attr_rc != hipSuccess) return ISIC_ERR_LAUNCH;
+  hipLaunchKernelGGL((gemm_f16_kernel<GELU, RES>), grid, dim3(1024), G_LDS, stream, a);
+  return isic_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int isic_gemm_f16(const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* residual, uint16_t* C,
+                  int M, int N, int K, int act, int residual_rows, void* stream) {
+  ISIC_CHECK_ARG(M >= 0 && N > 0 && K > 0 && (act == 0 || act == 1) && residual_rows >= 0);
+  if (M == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(A && W && C);
+  ISIC_CHECK_ARG(residual || residual_rows == 0);
+  if (N % GN != 0 || K % 64 != 0) return ISIC_ERR_UNSUPPORTED;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cus = n;
+  }
+  GemmF16Args a;
+  a.A = A; a.W = W; a.bias = bias; a.res = residual; a.C = C;
+  a.M = M; a.N = N; a.K = K; a.Ktiles = K / 64; a.act = act; a.res_rows = residual_rows;
+  a.mtiles = (M + GM - 1) / GM;
+  const int nslices = N / GN;
+  int gx = cus / nslices;
+  if (gx < 1) gx = 1;
+  if (gx > a.mtiles) gx = a.mtiles;
+  a.tiles_per_block = (a.mtiles + gx - 1) / gx;
+  gx = (a.mtiles + a.tiles_per_block - 1) / a.tiles_per_block;
+  const dim3 grid(gx, nslices);
+  hipStream_t s = as_stream(stream);
+  if (act == 1) return residual ? ISIC_ERR_UNSUPPORTED : launch_g16<true, false>(a, grid, s);   // GELU + residual: not a ViT layer
+  return residual ? launch_g16<false, true>(a, grid, s) : launch_g16<false, false>(a, grid, s);
+}
+
+}  // extern "C"

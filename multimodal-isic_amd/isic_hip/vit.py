@@ -1,0 +1,158 @@
+"""ViT-S/16 patch encoder, fp16 on MFMA -- the frozen encoder of BASELINE.json configs[4].
+
+The reference's patch encoder is an un-vendored ConvMAE conv-ViT run frozen: ``model.eval()``, ``torch.no_grad()``,
+``forward(images, mask_ratio=0) -> latent[B, 196, 768]`` (`save_latent.py:42-60`).  Its code and weights are not in the
+tree, so this is the build's own ViT-S/16 (timm `vit_small_patch16_224` parameter names, no class token: the reference
+consumes the 196 patch tokens only, `save_latent.py:56-60,77`).  Inference only, like the reference's use of it.
+
+Every layer is one launch of the C ABI: `isic_vit_patchify_f16`, `isic_gemm_f16` (bias, GELU, residual / position
+embedding fused into the epilogue), `isic_layernorm_f16`, `isic_attention_f16`.  The residual stream and all
+activations are fp16 in HBM ([N*196, 384] rows), arithmetic is fp32 inside the kernels.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from .lib import IsicHipError, call
+
+_F16 = torch.float16
+
+
+class ViTSmallEncoder(nn.Module):
+    def __init__(self, img_size=224, patch=16, in_ch=3, dim=384, depth=12, heads=6, mlp_ratio=4, seed=0):
+        super().__init__()
+        if dim % 128 != 0 or dim // heads != 64 or patch % 8 != 0 or img_size % patch != 0:
+            raise ValueError("ViTSmallEncoder: dim % 128 == 0, head width 64, patch % 8 == 0, img_size % patch == 0")
+        self.img_size, self.patch, self.in_ch, self.dim, self.depth, self.heads = img_size, patch, in_ch, dim, depth, heads
+        self.mlp = dim * mlp_ratio
+        self.tokens = (img_size // patch) ** 2
+        if self.tokens > 208:
+            raise ValueError("ViTSmallEncoder: at most 208 tokens per image (attention kernel)")
+        self.feature_dim = dim
+        g = torch.Generator().manual_seed(seed)
+
+        def P(*shape, scale):
+            return nn.Parameter(torch.randn(*shape, generator=g) * scale)
+        self._names = []
+
+        def add(name, param):
+            self._names.append(name)
+            self.register_parameter(name.replace(".", "__"), param)
+        add("patch_embed.proj.weight", P(dim, in_ch, patch, patch, scale=1.0 / math.sqrt(in_ch * patch * patch)))
+        add("patch_embed.proj.bias", nn.Parameter(torch.zeros(dim)))
+        add("pos_embed", P(1, self.tokens, dim, scale=0.02))
+        for i in range(depth):
+            b = f"blocks.{i}"
+            add(f"{b}.norm1.weight", nn.Parameter(torch.ones(dim))); add(f"{b}.norm1.bias", nn.Parameter(torch.zeros(dim)))
+            add(f"{b}.attn.qkv.weight", P(3 * dim, dim, scale=0.02)); add(f"{b}.attn.qkv.bias", nn.Parameter(torch.zeros(3 * dim)))
+            add(f"{b}.attn.proj.weight", P(dim, dim, scale=0.02)); add(f"{b}.attn.proj.bias", nn.Parameter(torch.zeros(dim)))
+            add(f"{b}.norm2.weight", nn.Parameter(torch.ones(dim))); add(f"{b}.norm2.bias", nn.Parameter(torch.zeros(dim)))
+            add(f"{b}.mlp.fc1.weight", P(self.mlp, dim, scale=0.02)); add(f"{b}.mlp.fc1.bias", nn.Parameter(torch.zeros(self.mlp)))
+            add(f"{b}.mlp.fc2.weight", P(dim, self.mlp, scale=0.02)); add(f"{b}.mlp.fc2.bias", nn.Parameter(torch.zeros(dim)))
+        add("norm.weight", nn.Parameter(torch.ones(dim))); add("norm.bias", nn.Parameter(torch.zeros(dim)))
+        for p in self.parameters():
+            p.requires_grad_(False)                    # frozen, as in save_latent.py:51-53
+        self._w16 = None                               # fp16 copies of the matrices, made once per weight version
+        self._w16_key = None
+        self.eval()
+
+    # ------------------------------------------------------------------ timm-named state_dict
+    def _get(self, name):
+        return self._parameters[name.replace(".", "__")]
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        out = destination if destination is not None else {}
+        for n in self._names:
+            p = self._get(n)
+            out[prefix + n] = p if keep_vars else p.detach()
+        return out
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        missing = [n for n in self._names if n not in state_dict]
+        unexpected = [k for k in state_dict if k not in self._names]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"ViTSmallEncoder.load_state_dict: missing {missing[:4]}, unexpected {unexpected[:4]}")
+        with torch.no_grad():
+            for n in self._names:
+                if n in state_dict:
+                    src = state_dict[n]
+                    dst = self._get(n)
+                    if tuple(src.shape) != tuple(dst.shape):
+                        raise RuntimeError(f"size mismatch for {n}: {tuple(src.shape)} vs {tuple(dst.shape)}")
+                    dst.copy_(src)
+        self._w16_key = None
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    def train(self, mode=True):
+        if mode:
+            raise IsicHipError("ViTSmallEncoder is a frozen inference encoder (save_latent.py:51-53): no train() mode")
+        return super().train(False)
+
+    # ------------------------------------------------------------------ forward
+    def _prepare(self, device):
+        key = tuple((self._get(n).data_ptr(), self._get(n)._version) for n in self._names)
+        if self._w16 is not None and key == self._w16_key:
+            return self._w16
+        w = {}
+        for n in self._names:
+            p = self._get(n).detach()
+            if p.device != device:
+                raise IsicHipError("ViTSmallEncoder: move the module to the GPU first (.to('cuda'))")
+            if n == "patch_embed.proj.weight":
+                w[n] = p.reshape(self.dim, -1).to(_F16).contiguous()
+            elif n == "pos_embed":
+                w[n] = p.reshape(self.tokens, self.dim).to(_F16).contiguous()
+            elif n.endswith(".weight") and p.dim() == 2:
+                w[n] = p.to(_F16).contiguous()
+            else:
+                w[n] = p.float().contiguous()                                      # biases, LayerNorm affine: fp32
+        self._w16, self._w16_key = w, key
+        return w
+
+    @torch.no_grad()
+    def run_tokens(self, images, depth=None):
+        """images[N,3,H,W] (fp32; other float types are converted) on the GPU -> tokens[N, 196, 384] fp32."""
+        if images.dim() != 4 or images.shape[1] != self.in_ch or images.shape[2] != self.img_size or images.shape[3] != self.img_size:
+            raise ValueError(f"expected images[N,{self.in_ch},{self.img_size},{self.img_size}], got {tuple(images.shape)}")
+        if not images.is_cuda:
+            raise IsicHipError("ViTSmallEncoder runs on the MI355X only (no CPU fallback)")
+        dev = images.device
+        w = self._prepare(dev)
+        x_in = images.float().contiguous()
+        N, T, D, H = x_in.shape[0], self.tokens, self.dim, self.heads
+        M = N * T
+        K0 = self.in_ch * self.patch * self.patch
+        rows = torch.empty((M, K0), device=dev, dtype=_F16)
+        call("isic_vit_patchify_f16", x_in, rows, N, self.in_ch, self.img_size, self.img_size, self.patch)
+        x = torch.empty((M, D), device=dev, dtype=_F16)
+        call("isic_gemm_f16", rows, w["patch_embed.proj.weight"], w["patch_embed.proj.bias"], w["pos_embed"], x, M, D, K0, 0, T)
+        del rows
+        h = torch.empty((M, D), device=dev, dtype=_F16)
+        qkv = torch.empty((M, 3 * D), device=dev, dtype=_F16)
+        att = torch.empty((M, D), device=dev, dtype=_F16)
+        hid = torch.empty((M, self.mlp), device=dev, dtype=_F16)
+        x2 = torch.empty_like(x)
+        for i in range(self.depth if depth is None else depth):
+            b = f"blocks.{i}"
+            call("isic_layernorm_f16", x, w[f"{b}.norm1.weight"], w[f"{b}.norm1.bias"], h, None, M, D, 1e-6)
+            call("isic_gemm_f16", h, w[f"{b}.attn.qkv.weight"], w[f"{b}.attn.qkv.bias"], None, qkv, M, 3 * D, D, 0, 0)
+            call("isic_attention_f16", qkv, att, N, T, H, D // H)
+            call("isic_gemm_f16", att, w[f"{b}.attn.proj.weight"], w[f"{b}.attn.proj.bias"], x, x2, M, D, D, 0, 0)
+            call("isic_layernorm_f16", x2, w[f"{b}.norm2.weight"], w[f"{b}.norm2.bias"], h, None, M, D, 1e-6)
+            call("isic_gemm_f16", h, w[f"{b}.mlp.fc1.weight"], w[f"{b}.mlp.fc1.bias"], None, hid, M, self.mlp, D, 1, 0)
+            call("isic_gemm_f16", hid, w[f"{b}.mlp.fc2.weight"], w[f"{b}.mlp.fc2.bias"], x2, x, M, D, self.mlp, 0, 0)
+        out = torch.empty((M, D), device=dev, dtype=torch.float32)
+        call("isic_layernorm_f16", x, w["norm.weight"], w["norm.bias"], None, out, M, D, 1e-6)
+        return out.view(N, T, D)
+
+    def forward(self, images):
+        """Mean-pooled 384-d feature per image (what a MIL bag of patches consumes)."""
+        return self.run_tokens(images).mean(dim=1)
+
+    def flops_per_image(self):
+        T, D, Hm = self.tokens, self.dim, self.mlp
+        per_block = 2 * T * (D * 3 * D + D * D + 2 * D * Hm) + 4 * T * T * D
+        return 2 * T * D * self.in_ch * self.patch ** 2 + self.depth * per_block

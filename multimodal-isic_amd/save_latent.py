@@ -134,7 +134,11 @@ def extract_latents(config, path, remove_background=False, datasets=None, batch_
             return {"image": img, "mask": m}
         datasets = (DermDataset(df_tv, radiomics=None, transform=transform), DermDataset(df_te, radiomics=None, transform=transform))
     loaders = [DataLoader(d, batch_size=batch_size, shuffle=False) for d in datasets]
-    enc = ResNet18Encoder().to(device)
+    if str(config.get("encoder", "resnet18")).lower() in ("vit_s16", "vit-s/16", "vit_small_patch16_224"):
+        from isic_hip.vit import ViTSmallEncoder                # BASELINE.json configs[4]: ViT-S/16, fp16, 196 x 384 tokens
+        enc = ViTSmallEncoder().to(device)
+    else:
+        enc = ResNet18Encoder().to(device)
     ckpt = os.path.join(os.getcwd(), config.get("model_path", "models"), path)
     if os.path.exists(ckpt):
         enc.load_state_dict(torch.load(ckpt, map_location=device, weights_only=True), strict=False)          # :46-48
