@@ -95,61 +95,73 @@ __global__ __launch_bounds__(256) void layernorm_f16_kernel(const unsigned short
 }
 
 // ---------------------------------------------------------------- attention
-// One block (4 waves) per (image, head): T <= 208 tokens, head width 64.  Q, K row-major in LDS ([token][64], 16-byte
-// chunks XOR-swizzled by token & 7), V transposed ([d][token], so that the P.V B-operand is two 8-byte reads).  A wave
-// owns query tiles of 16: S^T = K.Q^T on v_mfma_f32_16x16x32_f16 (13 key tiles x 2 k-steps; a lane then holds, for ITS
-// query l % 16, the scores of keys 16t + 4(l/16) + r), softmax over keys = in-lane over the 52 values + two xor
-// shuffles; the probabilities are already in the A-operand position of O = P.V up to a permutation of the contraction
-// index, which is applied to V's rows instead (k-slot 8(l/16) + e <-> key 32u + 16(e/4) + 4(l/16) + e%4).
+// One block (8 waves) per (image, head): T <= 208 tokens, head width 64.  K row-major in LDS ([token][64], 16-byte
+// chunks XOR-swizzled by token & 7), V transposed ([d][token], so that the P.V B-operand is two 8-byte reads); Q is
+// never staged: a wave reads the two 16-byte fragments of its 16 queries straight from global memory.  72 KB of LDS:
+// two blocks per CU, so one block's loads overlap the other's arithmetic.  A wave owns query tiles of 16: S^T = K.Q^T on
+// v_mfma_f32_16x16x32_f16 (13 key tiles x 2 k-steps; a lane then holds, for ITS query l % 16, the scores of keys
+// 16t + 4(l/16) + r), softmax over keys = in-lane over the 52 values + two xor shuffles; the probabilities are already
+// in the A-operand position of O = P.V up to a permutation of the contraction index, which is applied to V's rows
+// instead (k-slot 8(l/16) + e <-> key 32u + 16(e/4) + 4(l/16) + e%4).
 constexpr int AT_TMAX = 208, AT_KPAD = 224, AT_VPITCH = 232;         // tokens padded to 13 x 16 (scores) / 7 x 32 (P.V)
-constexpr int AT_Q = AT_TMAX * 128, AT_K = AT_TMAX * 128, AT_V = 64 * AT_VPITCH * 2, AT_O = 4 * 16 * 128;
-constexpr int AT_LDS = AT_Q + AT_K + AT_V + AT_O;
+constexpr int AT_WAVES = 8;
+constexpr int AT_K = AT_TMAX * 128, AT_V = 64 * AT_VPITCH * 2, AT_O = AT_WAVES * 16 * 128;
+constexpr int AT_LDS = AT_K + AT_V + AT_O;
 
-__global__ __launch_bounds__(256) void attention_f16_kernel(const unsigned short* __restrict__ qkv,
-                                                             unsigned short* __restrict__ out, int T, int heads,
-                                                             float scale_log2e) {
+__global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_f16_kernel(const unsigned short* __restrict__ qkv,
+                                                                          unsigned short* __restrict__ out, int T,
+                                                                          int heads, float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* Qs = smem;
-  unsigned char* Ks = smem + AT_Q;
-  unsigned short* Vt = reinterpret_cast<unsigned short*>(smem + AT_Q + AT_K);
+  unsigned char* Ks = smem;
+  unsigned short* Vt = reinterpret_cast<unsigned short*>(smem + AT_K);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int img = blockIdx.x / heads, head = blockIdx.x - img * heads;
   const int D = heads * 64, ld = 3 * D;                               // qkv row: [q heads*64 | k heads*64 | v heads*64]
   const unsigned short* base = qkv + (size_t)img * T * ld + head * 64;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int qtiles = (T + 15) >> 4;
 
-  // ---- stage Q, K (swizzled rows of 128 B) and V^T; rows >= T are zero
-  for (int idx = tid; idx < AT_TMAX * 8; idx += 256) {
-    const int t = idx >> 3, ch = idx & 7;
-    u32x4 q = {0u, 0u, 0u, 0u}, k = q;
-    if (t < T) {
-      q = *reinterpret_cast<const u32x4*>(base + (size_t)t * ld + ch * 8);
-      k = *reinterpret_cast<const u32x4*>(base + (size_t)t * ld + D + ch * 8);
-    }
-    *reinterpret_cast<u32x4*>(Qs + t * 128 + ((ch ^ (t & 7)) << 4)) = q;
-    *reinterpret_cast<u32x4*>(Ks + t * 128 + ((ch ^ (t & 7)) << 4)) = k;
-  }
-  for (int idx = tid; idx < AT_KPAD * 8; idx += 256) {
-    const int t = idx >> 3, ch = idx & 7;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (t < T) v = *reinterpret_cast<const u32x4*>(base + (size_t)t * ld + 2 * D + ch * 8);
+  // ---- this wave's first query fragments (global -> registers), in flight while K and V are staged
+  auto load_q = [&](int qt, f16x8 (&qf)[2]) {
+    const int q = min(qt * 16 + fr, T - 1);                           // rows >= T: any valid row, never stored
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      Vt[(ch * 8 + 2 * e) * AT_VPITCH + t] = (unsigned short)(v[e] & 0xFFFFu);
-      Vt[(ch * 8 + 2 * e + 1) * AT_VPITCH + t] = (unsigned short)(v[e] >> 16);
+    for (int ks = 0; ks < 2; ++ks)
+      qf[ks] = *reinterpret_cast<const f16x8*>(base + (size_t)q * ld + (ks * 4 + fg) * 8);
+  };
+  f16x8 qf[2];
+  if (wave < qtiles) load_q(wave, qf);
+
+  // ---- stage K (swizzled rows of 128 B) and V^T; rows >= T are zero.  All of a thread's loads first, then the stores.
+  constexpr int KV_PER = (AT_KPAD * 8 + AT_WAVES * 64 - 1) / (AT_WAVES * 64);      // 4 vectors of K and of V per thread
+  u32x4 kr[KV_PER], vr[KV_PER];
+#pragma unroll
+  for (int u = 0; u < KV_PER; ++u) {
+    const int idx = tid + u * AT_WAVES * 64, t = idx >> 3, ch = idx & 7;
+    kr[u] = (u32x4){0u, 0u, 0u, 0u};
+    vr[u] = kr[u];
+    if (t < T) {
+      kr[u] = *reinterpret_cast<const u32x4*>(base + (size_t)t * ld + D + ch * 8);
+      vr[u] = *reinterpret_cast<const u32x4*>(base + (size_t)t * ld + 2 * D + ch * 8);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < KV_PER; ++u) {
+    const int idx = tid + u * AT_WAVES * 64, t = idx >> 3, ch = idx & 7;
+    if (t < AT_TMAX) *reinterpret_cast<u32x4*>(Ks + t * 128 + ((ch ^ (t & 7)) << 4)) = kr[u];
+    if (t < AT_KPAD) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned w = vr[u][e];
+        Vt[(ch * 8 + 2 * e) * AT_VPITCH + t] = (unsigned short)(w & 0xFFFFu);
+        Vt[(ch * 8 + 2 * e + 1) * AT_VPITCH + t] = (unsigned short)(w >> 16);
+      }
     }
   }
   __syncthreads();
 
-  const int fr = lane & 15, fg = lane >> 4;
-  unsigned char* Os = smem + AT_Q + AT_K + AT_V + wave * (16 * 128);
-  const int qtiles = (T + 15) >> 4;
-  for (int qt = wave; qt < qtiles; qt += 4) {
+  unsigned char* Os = smem + AT_K + AT_V + wave * (16 * 128);
+  for (int qt = wave; qt < qtiles; qt += AT_WAVES) {
     // ---- S^T tile row: keys x this tile's 16 queries
-    const int qrow = qt * 16 + fr;                                    // < AT_TMAX (zero rows beyond T)
-    f16x8 qf[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-      qf[ks] = *reinterpret_cast<const f16x8*>(Qs + qrow * 128 + (((ks * 4 + fg) ^ (qrow & 7)) << 4));
     f32x4 s[13];
 #pragma unroll
     for (int kt = 0; kt < 13; ++kt) {
@@ -161,6 +173,7 @@ __global__ __launch_bounds__(256) void attention_f16_kernel(const unsigned short
         s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], s[kt], 0, 0, 0);   // D[key 4fg+r][query fr]
       }
     }
+    if (qt + AT_WAVES < qtiles) load_q(qt + AT_WAVES, qf);            // next tile's queries under the softmax
     // ---- softmax over the keys of query fr (base-2 exponent, scale folded in); keys >= T masked out
     float mx = -INFINITY;
 #pragma unroll
@@ -272,7 +285,7 @@ int isic_attention_f16(const uint16_t* qkv, uint16_t* out, int n_images, int tok
   });
   if (attr_rc != hipSuccess) return ISIC_ERR_LAUNCH;
   const float scale_log2e = 0.125f * 1.4426950408889634f;            // 1 / sqrt(64), base-2 exponent
-  hipLaunchKernelGGL(attention_f16_kernel, dim3(n_images * heads), dim3(256), AT_LDS, as_stream(stream), qkv, out, tokens,
+  hipLaunchKernelGGL(attention_f16_kernel, dim3(n_images * heads), dim3(AT_WAVES * 64), AT_LDS, as_stream(stream), qkv, out, tokens,
                      heads, scale_log2e);
   return isic_launch_status();
 }
