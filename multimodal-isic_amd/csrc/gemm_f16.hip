@@ -27,7 +27,8 @@ constexpr int GM = 256, GN = 128;
 constexpr int G_A = GM * 128, G_B = GN * 128, G_STAGE = G_A + G_B;   // bytes per K-tile
 constexpr int G_NST = 3;
 constexpr int G_PER_IT = 6;                 // DMAs per staging wave and K-tile
-constexpr int G_LDS = G_NST * G_STAGE + 1024 + 512;                  // ring | DMA scratch | the slice's 128 biases
+constexpr int G_MAXSPB = 4;                 // column slices a block may own
+constexpr int G_LDS = G_NST * G_STAGE + 1024 + G_MAXSPB * 512;       // ring | DMA scratch | the block's biases
 
 struct GemmF16Args {
   const unsigned short* A;      // [M][K]
@@ -36,6 +37,7 @@ struct GemmF16Args {
   const unsigned short* res;    // [M][N] (res_rows == 0) or [res_rows][N] broadcast over m % res_rows, or null
   unsigned short* C;            // [M][N]
   int M, N, K, Ktiles, act, res_rows, mtiles, tiles_per_block;
+  int spb;                      // consecutive 128-column slices per block (blockIdx.y owns slices y*spb .. +spb)
 };
 
 __device__ __attribute__((aligned(256))) unsigned char g_g16_zero_page[256];
@@ -62,9 +64,12 @@ __global__ __launch_bounds__(1024) void gemm_f16_kernel(GemmF16Args a) {
   constexpr int off_scr = G_NST * G_STAGE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n0 = blockIdx.y * GN;
+  // work items of a block: (row tile, slice) with the slice fastest -- the A tile just staged for slice j is re-read
+  // from L2 for slice j + 1, and the blocks (x, 0..gridDim.y-1) share an XCD (host: gridDim.x % 8 == 0)
+  const int spb = a.spb;
+  const int nbase = blockIdx.y * spb * GN;
   const int t_begin = blockIdx.x * a.tiles_per_block;
-  const int ntl = min(a.mtiles - t_begin, a.tiles_per_block);
+  const int ntl = min(a.mtiles - t_begin, a.tiles_per_block) * spb;        // work items
   if (ntl <= 0) return;                                    // whole block: no barrier has been reached yet
   const int KT = a.Ktiles;
   const int total_it = ntl * KT;
@@ -80,11 +85,13 @@ __global__ __launch_bounds__(1024) void gemm_f16_kernel(GemmF16Args a) {
     //   wn*64 + 32*(j>>1) + 8*(rho>>2) + 4*(j&1) + (rho&3)   with wn = sr>>6, j = (sr>>4)&3, rho = sr&15
     // so that a lane's results of MFMA tiles 2t', 2t'+1 are EIGHT CONSECUTIVE columns (conv_halo.hip)
     const int chan0 = (sw >> 2) * 64 + ((sw & 3) >> 1) * 32 + (r8 >> 2) * 8 + (sw & 1) * 4 + (r8 & 3);   // t = 0; t = 1: + 16
-    const unsigned short* wrow = a.W + (size_t)(n0 + chan0) * a.K + gch * 8;
+    const unsigned short* wrow = nullptr;
 
     const unsigned short* a_ptr[4];
     bool a_ok[4];
-    auto tile_rows = [&](int tl) {
+    auto tile_rows = [&](int item) {
+      const int tl = item / spb, j = item - tl * spb;
+      wrow = a.W + (size_t)(nbase + j * GN + chan0) * a.K + gch * 8;
       const int m0 = (t_begin + tl) * GM;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -124,15 +131,17 @@ __global__ __launch_bounds__(1024) void gemm_f16_kernel(GemmF16Args a) {
     const int wm = wave >> 1, wn = wave & 1;
     const unsigned aoff0 = (unsigned)((wm * 64 + fr) * 128 + ((fg ^ (fr & 7)) << 4));
     const unsigned boff0 = (unsigned)(G_A + (wn * 64 + fr) * 128 + ((fg ^ (fr & 7)) << 4));
-    const unsigned chan = (unsigned)(n0 + wn * 64 + fg * 8);
-    // the slice's biases in LDS (read back per 4 columns in the epilogue: no registers held across the K loop)
-    float* bias_lds = reinterpret_cast<float*>(smem + off_scr + 1024);
-    if (tid < GN) bias_lds[tid] = a.bias ? a.bias[n0 + tid] : 0.f;
+    // the block's biases in LDS (read back per 4 columns in the epilogue: no registers held across the K loop)
+    float* bias_all = reinterpret_cast<float*>(smem + off_scr + 1024);
+    if (tid < spb * GN) bias_all[tid] = a.bias ? a.bias[nbase + tid] : 0.f;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // visible after the first K-tile barrier
 
     int it = 0;
-    for (int tl = 0; tl < ntl; ++tl) {
+    for (int item = 0; item < ntl; ++item) {
+      const int tl = item / spb, j = item - tl * spb;
       const int m0 = (t_begin + tl) * GM;
+      const unsigned chan = (unsigned)(nbase + j * GN + wn * 64 + fg * 8);
+      const float* bias_lds = bias_all + j * GN;
       f32x4 acc[4][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -241,15 +250,27 @@ int isic_gemm_f16(const uint16_t* A, const uint16_t* W, const float* bias, const
   a.M = M; a.N = N; a.K = K; a.Ktiles = K / 64; a.act = act; a.res_rows = residual_rows;
   a.mtiles = (M + GM - 1) / GM;
   const int nslices = N / GN;
-  // All N-slices of one row range must share an L2: workgroup w runs on XCD w % 8 and w = x + y * gx, so gx is kept a
-  // multiple of 8 -- the blocks (x, 0..nslices-1) then sit on one XCD, walk the same A tiles in step, and A is read from
-  // HBM once instead of once per slice (N = 384: fc2 691 -> 788, proj 473 -> 541 TFLOP/s).
-  int gx = cus / nslices;
-  if (gx >= 8 && nslices <= 4) gx &= ~7;            // (with 9 or 12 slices the rounding idles 16-25 % of the CUs: slower)
-  if (gx < 1) gx = 1;
-  if (gx > a.mtiles) gx = a.mtiles;
+  // All N-slices of one row range must share an L2: workgroup w runs on XCD w % 8 and w = x + y * gx, so gx is a multiple
+  // of 8 -- the blocks (x, 0..gy-1) then sit on one XCD and walk the same A tiles in step -- and a block owns `spb`
+  // consecutive slices (slice fastest), chosen so that gx * gy fills the chip: 12 slices -> 3 per block x 4 x 64 blocks,
+  // 9 -> 3 x 3 x 80, 3 -> 1 x 3 x 80 (qkv 652 -> 569 us, fc2 691 -> 629 us at 2048 images).  A is then read from HBM about
+  // once instead of once per slice.
+  int spb = 1, gx = 1, best = -1;
+  for (int c = 1; c <= G_MAXSPB; ++c) {
+    if (nslices % c != 0) continue;
+    const int gy_c = nslices / c;
+    int gx_c = cus / gy_c;
+    if (gx_c >= 8) gx_c &= ~7;
+    if (gx_c < 1) gx_c = 1;
+    if (gx_c > a.mtiles) gx_c = a.mtiles;
+    // a block re-reads its A tile one tile-time later: the A tiles an XCD touches meanwhile must fit its 4 MB L2
+    if (c > 1 && (int64_t)((gx_c + 7) / 8) * GM * K * 2 > (3 << 20)) continue;
+    if (gx_c * gy_c > best) { best = gx_c * gy_c; spb = c; gx = gx_c; }
+  }
+  const int gy = nslices / spb;
+  a.spb = spb;
   a.tiles_per_block = (a.mtiles + gx - 1) / gx;
-  const dim3 grid(gx, nslices);
+  const dim3 grid(gx, gy);
   hipStream_t s = as_stream(stream);
   if (act == 1) return residual ? ISIC_ERR_UNSUPPORTED : launch_g16<1, false>(a, grid, s);   // GELU + residual: not a ViT layer
   return residual ? launch_g16<0, true>(a, grid, s) : launch_g16<0, false>(a, grid, s);

@@ -76,3 +76,17 @@ def test_extract_latents_contract_and_patch_frames():
     out2 = sl.extract_latents({"device": DEV, "seed": 42, "pca": True}, "missing.pth", True, datasets=(tv, te), batch_size=8)
     d = out2[0]["patch_latent_pca"].iloc[0].shape[0]
     assert 0 < d < 256 and out2[1]["patch_latent_pca"].iloc[0].shape[0] == d
+
+
+def test_extract_latents_with_the_vit_s16_encoder():
+    """BASELINE.json configs[4]: ``encoder: vit_s16`` in the config swaps the frozen encoder for the fp16 ViT-S/16 --
+    same return contract, 196 tokens of 384 channels."""
+    import save_latent as sl
+    cfg = {"device": DEV, "seed": 42, "pca": False, "encoder": "vit_s16"}
+    tv, te = sl.SyntheticDermImages(n=5, seed=1), sl.SyntheticDermImages(n=3, seed=2)
+    ptr, pte, pool_tr, pool_te, raw_tr, raw_te = sl.extract_latents(cfg, "missing.pth", datasets=(tv, te), batch_size=4)
+    assert len(pool_tr) == 5 and len(raw_te) == 3 and raw_tr["latent"].iloc[0].shape == (196, 384)
+    lat = np.stack(list(raw_tr["latent"]))
+    assert np.isfinite(lat).all() and lat.std() > 0.1
+    assert np.allclose(pool_tr["latent_pooled_mean"].iloc[2], raw_tr["latent"].iloc[2].mean(axis=0), atol=1e-5)
+    assert len(ptr) == 5 * 196 and ptr["patch_latent"].iloc[0].shape == (384,)
