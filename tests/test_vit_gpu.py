@@ -150,3 +150,47 @@ def test_encoder_is_deterministic_and_batch_invariant():
     assert torch.equal(a, b)
     c = enc.run_tokens(x[1:3])
     assert torch.equal(a[1:3], c)                              # an image's tokens do not depend on its batch
+
+
+def test_configs4_pipeline_vit_tokens_to_teacher_to_heterophily_aware_gnn():
+    """BASELINE.json configs[4] end to end at toy scale: images -> frozen ViT-S/16 tokens (fp16 MFMA) -> attention-MIL
+    teacher trained on the 196-token bags -> teacher outputs, dominant classes and k-NN graphs kept on the device
+    (pipeline.py) -> edge heterophily -> a heterophily-aware GNN (GCNII) trained on those graphs."""
+    import numpy as np
+    import measure_heterophily as mh
+    import pipeline
+    from gnn_models import GraphMIL
+    from isic_hip import train as T
+    from isic_hip.vit import ViTSmallEncoder
+    from utils_g_mil import AttentionMIL_teacher
+    dev = torch.device(DEV)
+    torch.manual_seed(0)
+    enc = ViTSmallEncoder(seed=3).to(dev)
+    G, C = 28, 4
+    g = torch.Generator().manual_seed(5)
+    labels = np.arange(G) % C
+    images = torch.randn(G, 3, 224, 224, generator=g) * 0.5
+    for i, y in enumerate(labels):                                   # a class-dependent pattern in one quadrant
+        images[i, :, (y // 2) * 112:(y // 2) * 112 + 112, (y % 2) * 112:(y % 2) * 112 + 112] += 1.5
+    tokens = enc.run_tokens(images.to(dev))                            # [G, 196, 384] fp32 on the device
+    assert tokens.is_cuda and tokens.shape == (G, 196, 384) and bool(torch.isfinite(tokens).all())
+    bags = [t for t in tokens.cpu().numpy()]
+    tr_i, va_i = np.arange(0, 20), np.arange(20, G)
+    teacher = AttentionMIL_teacher(384, 64, 32, dropout=0.1, num_classes=C).to(dev)
+    res = T.train_teacher_fold(teacher, [bags[i] for i in tr_i], labels[tr_i], [bags[i] for i in va_i], labels[va_i],
+                               lr=2e-3, epochs=6, patience=6, bags_per_step=4, device=dev, log=lambda *a, **k: None)
+    assert np.isfinite(res["history"][-1]["val_loss"])
+    ids = [f"img_{i}" for i in range(G)]
+    outs = [pipeline.collect_teacher_outputs_device(teacher, tokens[idx], labels[idx], [ids[i] for i in idx], dev)
+            for idx in (tr_i, va_i)]
+    assert outs[0].x.is_cuda and outs[0].knn.shape == (20, 196, 16)
+    ei = outs[0].knn_edge_index(8)
+    het = mh.compute_edge_heterophily_batch([b for b in outs[0].x.cpu().numpy()], [p for p in outs[0].patch_probs.cpu().numpy()],
+                                            [d for d in outs[0].dominant_class.cpu().numpy()], [e for e in ei.cpu().numpy()], device=DEV)
+    assert len(het) == 20 and all(np.isfinite(np.asarray(v, dtype=np.float64)).all() for h in het for v in h.values())
+    torch.manual_seed(1)
+    gnn = GraphMIL(384, "gcnii", 64, 3, 0.1, att_dim=32, att_heads=4, pool_dropout=0.1, classifier_dim=32,
+                   classifier_light=True, num_classes=C).to(dev)
+    vm, tm, best = pipeline.train_gnn_from_teacher(gnn, outs[0], outs[1], outs[1], "knn8", lr=2e-3, epochs=4, graphs_per_step=4,
+                                                   num_classes=C, device=dev, rng=np.random.RandomState(2))
+    assert np.isfinite(vm["loss"]) and 0.0 <= vm["bacc"] <= 1.0 and best >= 1
