@@ -504,8 +504,10 @@ int conv2d_dispatch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N,
     }
   if (all.n == 0) return ISIC_OK;
   // short-K layers (stride-2 3x3 and its data gradient, 1x1 downsample): persistent blocks, register epilogue
-  if (Cout % 128 == 0 && !(stat_sum && addend) && cv.pgemm != 1 &&
-      (cv.pgemm == 2 || up != 1 || (down != 1 && Kh * Kw > 1) || (Kh == 1 && Kw == 1 && down == 1))) {
+  // (64-wide slices exist in conv_pgemm.hip but are not chosen: the data gradient of the 64 -> 128 stride-2 layer has 2-8
+  //  K-tiles per tile and ran 0.73 ms there against 0.63 ms in the one-tile-per-block kernel, whose blocks overlap)
+  if (Cout % 64 == 0 && !(stat_sum && addend) && cv.pgemm != 1 &&
+      (cv.pgemm == 2 || (Cout % 128 == 0 && (up != 1 || (down != 1 && Kh * Kw > 1) || (Kh == 1 && Kw == 1 && down == 1))))) {
     const int rc = isic_conv_pgemm_launch(all, s);
     return rc != ISIC_OK ? rc : isic_launch_status();
   }

@@ -30,15 +30,15 @@ namespace {
 
 using namespace isic_conv;
 
-constexpr int PM = 256, PN = 128;           // block tile
-constexpr int P_A = PM * 128, P_B = PN * 128, P_STAGE = P_A + P_B;   // bytes per K-tile
+constexpr int PM = 256;                     // block tile: PM pixels x PN output channels, PN = 128 or 64 (template)
+constexpr int P_A = PM * 128;               // bytes of A per K-tile
 constexpr int P_NST = 3;
-constexpr int P_PER_IT = 6;                 // DMAs per staging wave and K-tile
-constexpr int P_LDS = P_NST * P_STAGE + 1024 + 1024;                 // ring | DMA scratch | 256 floats of statistics
+constexpr int p_stage(int PN) { return P_A + PN * 128; }
+constexpr int p_lds(int PN) { return P_NST * p_stage(PN) + 1024 + 1024; }   // ring | DMA scratch | 2 PN floats of statistics
 
 struct PGemmArgs {
   ConvArgsN cls;
-  int nslices;          // Cout / 128
+  int nslices;          // Cout / PN
   int gfirst[5];        // class c owns blockIdx.x in [gfirst[c], gfirst[c+1]): blocks in proportion to its work
 };
 
@@ -63,8 +63,15 @@ __device__ __forceinline__ float pg_row16_sum(float v) {
   return v;
 }
 
-template <bool STATS, bool ADDEND>
+// PN = 64 (round 2, for convolutions with 64 outputs -- the data gradient of the 64 -> 128 stride-2 layer): the MFMA
+// waves stay 4 x 2 but own 64 x 32 (4 x 2 tiles), a stage holds 64 weight rows (one DMA piece per staging wave).
+template <int PN, bool STATS, bool ADDEND>
 __global__ __launch_bounds__(1024) void conv_pgemm_kernel(PGemmArgs pa) {
+  constexpr int P_STAGE = p_stage(PN);
+  constexpr int P_PER_IT = 4 + PN / 64;       // DMAs per staging wave and K-tile
+  constexpr int NJ = PN / 32;                 // MFMA column tiles per wave
+  constexpr int NT = PN / 64;                 // 8-channel groups per lane in the epilogue
+  constexpr int WN = PN / 2;                  // columns per wave column
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   constexpr int off_scr = P_NST * P_STAGE, off_stat = off_scr + 1024;
@@ -102,7 +109,9 @@ __global__ __launch_bounds__(1024) void conv_pgemm_kernel(PGemmArgs pa) {
     // weights: stage rows sr = 16*sw + 8*t + r8 (t = 0, 1) hold output channel
     //   wn*64 + 32*(j>>1) + 8*(rho>>2) + 4*(j&1) + (rho&3)   with wn = sr>>6, j = (sr>>4)&3, rho = sr&15
     // so that a lane's results of MFMA tiles 2t', 2t'+1 are EIGHT CONSECUTIVE channels (conv_halo.hip)
-    const int chan0 = (sw >> 2) * 64 + ((sw & 3) >> 1) * 32 + (r8 >> 2) * 8 + (sw & 1) * 4 + (r8 & 3);   // t = 0; t = 1: + 16
+    //   PN = 64: one piece, rows sr = 8*sw + r8: wn = sr>>5, j = (sr>>4)&1, rho = sr&15 -> wn*32 + 8*(rho>>2) + 4*j + (rho&3)
+    const int chan0 = PN == 128 ? (sw >> 2) * 64 + ((sw & 3) >> 1) * 32 + (r8 >> 2) * 8 + (sw & 1) * 4 + (r8 & 3)   // t = 0; t = 1: + 16
+                                : (sw >> 2) * 32 + ((sw & 1) * 2 + (r8 >> 2)) * 8 + ((sw >> 1) & 1) * 4 + (r8 & 3);
     const size_t Ktot = (size_t)a.Kh * a.Kw * a.Cin;
     const unsigned short* wrow = a.w + (size_t)(n0 + chan0) * Ktot + gch * 8;
 
@@ -139,8 +148,12 @@ __global__ __launch_bounds__(1024) void conv_pgemm_kernel(PGemmArgs pa) {
         const void* src = ok ? (const void*)(a.in + (a_off[i] + toff)) : (const void*)zp;
         pg_glds16(src, live ? sbase + (unsigned)((sw + 8 * i) * 1024) : scr);
       }
-      pg_glds16(live ? (const void*)(wrow + koff) : (const void*)zp, live ? sbase + P_A + sw * 2048 : scr);
-      pg_glds16(live ? (const void*)(wrow + koff + (size_t)16 * Ktot) : (const void*)zp, live ? sbase + P_A + sw * 2048 + 1024 : scr);
+      if (PN == 128) {
+        pg_glds16(live ? (const void*)(wrow + koff) : (const void*)zp, live ? sbase + P_A + sw * 2048 : scr);
+        pg_glds16(live ? (const void*)(wrow + koff + (size_t)16 * Ktot) : (const void*)zp, live ? sbase + P_A + sw * 2048 + 1024 : scr);
+      } else {
+        pg_glds16(live ? (const void*)(wrow + koff) : (const void*)zp, live ? sbase + P_A + sw * 1024 : scr);
+      }
     };
 
     if (KT > 0) {
@@ -164,24 +177,24 @@ __global__ __launch_bounds__(1024) void conv_pgemm_kernel(PGemmArgs pa) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA may outlive the block's LDS allocation
   } else {
     // ===================================================================== MFMA waves
-    if (STATS && tid < 256) stats_lds[tid] = 0.f;
+    if (STATS && tid < 2 * PN) stats_lds[tid] = 0.f;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     const int fr = lane & 15, fg = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
     // fragment byte offsets inside a stage (rows 16 apart share the swizzle key row & 7: tile i / j = + 2048 i / j)
     const unsigned aoff0 = (unsigned)((wm * 64 + fr) * 128 + ((fg ^ (fr & 7)) << 4));
-    const unsigned boff0 = (unsigned)(P_A + (wn * 64 + fr) * 128 + ((fg ^ (fr & 7)) << 4));
+    const unsigned boff0 = (unsigned)(P_A + (wn * WN + fr) * 128 + ((fg ^ (fr & 7)) << 4));
     const bool dense = (a.ostep == 1 && a.Hs == a.Hout && a.Ws == a.Wout);
 
     int it = 0;
     for (int tl = 0; tl < ntl; ++tl) {
       const int m0 = (t_begin + tl) * PM;
-      f32x4 acc[4][4];
+      f32x4 acc[4][NJ];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll 1
       for (int kt = 0; kt < KT; ++kt, ++it) {
@@ -189,23 +202,22 @@ __global__ __launch_bounds__(1024) void conv_pgemm_kernel(PGemmArgs pa) {
         const unsigned char* st = smem + (it % P_NST) * P_STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          bf16x8 af[4], bfr[4];
+          bf16x8 af[4], bfr[NJ];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            af[i] = *reinterpret_cast<const bf16x8*>(st + ((aoff0 ^ (unsigned)(ks << 6)) + i * 2048));
-            bfr[i] = *reinterpret_cast<const bf16x8*>(st + ((boff0 ^ (unsigned)(ks << 6)) + i * 2048));
-          }
+          for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + ((aoff0 ^ (unsigned)(ks << 6)) + i * 2048));
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(st + ((boff0 ^ (unsigned)(ks << 6)) + j * 2048));
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
       }
 
       // ---- register-only epilogue: lane (fg, fr) holds, for MFMA tiles (i, 2t) and (i, 2t+1), the eight consecutive
       //      output channels n0 + wn*64 + 32t + 8fg + {0..7} of sub-grid pixel m0 + wm*64 + i*16 + fr
-      const unsigned chan = (unsigned)(n0 + wn * 64 + fg * 8);
+      const unsigned chan = (unsigned)(n0 + wn * WN + fg * 8);
       unsigned off[4];
       bool valid[4];
 #pragma unroll
@@ -221,18 +233,18 @@ __global__ __launch_bounds__(1024) void conv_pgemm_kernel(PGemmArgs pa) {
         }
         off[i] = pix * (unsigned)a.Cout + chan;            // N*Hout*Wout*Cout < 2^31 (host check)
       }
-      u32x4 ad[4][2];
+      u32x4 ad[4][NT];
       if (ADDEND) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int t = 0; t < 2; ++t) ad[i][t] = *reinterpret_cast<const u32x4*>(a.addend + off[i] + t * 32);
+          for (int t = 0; t < NT; ++t) ad[i][t] = *reinterpret_cast<const u32x4*>(a.addend + off[i] + t * 32);
       }
-      unsigned sb = (unsigned)(wn * 64 + fg * 8 + (fr >> 3) * 128 + (fr & 7));
+      unsigned sb = (unsigned)(wn * WN + fg * 8 + (fr >> 3) * PN + (fr & 7));
       asm volatile("" : "+v"(sb));                         // the lane's statistics slot (value #fr of its channel group)
       lds_float* sp = stats_lds + sb;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NT; ++t) {
         float s8[8], q8[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) { s8[c] = 0.f; q8[c] = 0.f; }
@@ -281,29 +293,30 @@ __global__ __launch_bounds__(1024) void conv_pgemm_kernel(PGemmArgs pa) {
 
   if (STATS) {
     lds_barrier();                                         // all sixteen waves: every tile's partial sums are in LDS
-    if (tid < 256) {
-      const size_t slot = (size_t)((blockIdx.x + blockIdx.y) % a.stat_slots) * a.Cout + n0 + (tid & 127);
-      atomicAdd((tid < 128 ? a.stat_sum : a.stat_sumsq) + slot, (double)stats_lds[tid]);
+    if (tid < 2 * PN) {
+      const size_t slot = (size_t)((blockIdx.x + blockIdx.y) % a.stat_slots) * a.Cout + n0 + (tid & (PN - 1));
+      atomicAdd((tid < PN ? a.stat_sum : a.stat_sumsq) + slot, (double)stats_lds[tid]);
     }
   }
 }
 
-template <bool STATS, bool ADDEND>
+template <int PN, bool STATS, bool ADDEND>
 int launch_pgemm(const PGemmArgs& pa, dim3 grid, hipStream_t stream) {
   static std::once_flag once;
   static hipError_t attr_rc = hipSuccess;
   std::call_once(once, [] {
-    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pgemm_kernel<STATS, ADDEND>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pgemm_kernel<PN, STATS, ADDEND>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, p_lds(PN));
   });
   if (attr_rc != hipSuccess) return ISIC_ERR_LAUNCH;
-  hipLaunchKernelGGL((conv_pgemm_kernel<STATS, ADDEND>), grid, dim3(1024), P_LDS, stream, pa);
+  hipLaunchKernelGGL((conv_pgemm_kernel<PN, STATS, ADDEND>), grid, dim3(1024), p_lds(PN), stream, pa);
   return ISIC_OK;
 }
 
 }  // namespace
 
-// Called by isic_conv2d_igemm_bf16 (conv_igemm.hip) with the parity classes it has set up; Cout % 128 == 0.
+// Called by isic_conv2d_igemm_bf16 (conv_igemm.hip) with the parity classes it has set up; Cout % 64 == 0
+// (128-channel slices when Cout % 128 == 0, else 64-channel slices).
 int isic_conv_pgemm_launch(const isic_conv::ConvArgsN& classes, hipStream_t stream) {
   static int cus = 0;
   if (cus == 0) {
@@ -314,7 +327,8 @@ int isic_conv_pgemm_launch(const isic_conv::ConvArgsN& classes, hipStream_t stre
     cus = n;
   }
   const ConvArgs& a0 = classes.c[0];
-  if (a0.Cout % PN != 0 || classes.n < 1) return ISIC_ERR_UNSUPPORTED;
+  if (a0.Cout % 64 != 0 || classes.n < 1) return ISIC_ERR_UNSUPPORTED;
+  const int PN = a0.Cout % 128 == 0 ? 128 : 64;
   if (a0.stat_sum && a0.addend) return ISIC_ERR_UNSUPPORTED;
   PGemmArgs pa;
   pa.cls = classes;
@@ -348,7 +362,12 @@ int isic_conv_pgemm_launch(const isic_conv::ConvArgsN& classes, hipStream_t stre
   pa.gfirst[0] = 0;
   for (int i = 0; i < 4; ++i) pa.gfirst[i + 1] = pa.gfirst[i] + (i < classes.n ? g[i] : 0);
   const dim3 grid(pa.gfirst[classes.n], pa.nslices);
-  if (a0.stat_sum) return launch_pgemm<true, false>(pa, grid, stream);
-  if (a0.addend) return launch_pgemm<false, true>(pa, grid, stream);
-  return launch_pgemm<false, false>(pa, grid, stream);
+  if (PN == 128) {
+    if (a0.stat_sum) return launch_pgemm<128, true, false>(pa, grid, stream);
+    if (a0.addend) return launch_pgemm<128, false, true>(pa, grid, stream);
+    return launch_pgemm<128, false, false>(pa, grid, stream);
+  }
+  if (a0.stat_sum) return launch_pgemm<64, true, false>(pa, grid, stream);
+  if (a0.addend) return launch_pgemm<64, false, true>(pa, grid, stream);
+  return launch_pgemm<64, false, false>(pa, grid, stream);
 }

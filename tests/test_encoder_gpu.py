@@ -213,6 +213,8 @@ PGEMM_CASES = [  # N, Hin, Win, Cin, Cout, k, stride, pad -- forward geometry; t
     (260, 14, 14, 128, 256, 1, 2, 0),
     (64, 9, 11, 256, 512, 3, 2, 1),       # non-square, odd sizes: parity classes of different shapes
     (5, 7, 7, 256, 256, 3, 1, 1),         # a stride-1 layer forced through the kernel (variant digit 2)
+    (33, 12, 12, 128, 64, 3, 2, 1),       # 64 output channels forward: the 64-wide slice variant with fused statistics
+    (70, 56, 56, 64, 128, 3, 2, 1),       # layer2.0 conv1 at its real size: the data gradient has 64 outputs
 ]
 
 
@@ -254,7 +256,7 @@ def test_conv_pgemm_kernel(case):
     o = got.float().reshape(-1, Co).double()
     assert_close(gacc[0].cpu(), o.sum(0).cpu(), rtol=1e-5, atol=1e-3, what="fused sum")
     assert_close(gacc[1].cpu(), (o * o).sum(0).cpu(), rtol=1e-5, atol=1e-3, what="fused sumsq")
-    if Ci % 128 == 0:                     # the data gradient's output channels = Cin must fill a 128-wide slice
+    if Ci % 64 == 0:                      # the data gradient's output channels = Cin: 128- or 64-wide slices
         for addend in (False, True):
             a, b = dgrad(1100, addend), dgrad(2100, addend)
             torch.cuda.synchronize()
