@@ -283,6 +283,23 @@ int isic_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dw, int
  * dgrad copy [I][Kh][Kw][O] with both taps flipped (either may be NULL). */
 int isic_conv_weight_prep_bf16(const float* w_krsc, uint16_t* w_fwd, uint16_t* w_dgrad, int O, int I, int Kh, int Kw,
                                void* stream);
+/* Data gradient whose output is the gradient g of an activation z = ReLU(BatchNorm(y) [+ residual]) (ResNet BasicBlock:
+ * the data gradient of conv2 feeds bn1's backward, that of the next block's conv1 (+ identity addend) feeds bn2's).
+ * The epilogue applies the ReLU mask (relu_mask[rows][Cout/8], bit c = channel 8g + c, as written by
+ * isic_bn_apply_mask_bf16), stores out = dz = mask ? g (+ addend) : 0 and ADDS the per-channel sums BatchNorm's backward
+ * needs, sum dz and sum dz * y_raw, into sum_dz / sum_dzy[stat_slots][Cout] (zeroed by the caller) -- the separate
+ * reduction pass over (g, y) disappears, and for a block's last BatchNorm so does the materialised residual gradient
+ * (it IS dz).  isic_bn_bwd_finalize turns the sums into dgamma / dbeta; isic_bn_bwd_apply_bf16(dz, y_raw, relu = 0)
+ * finishes.  Geometry arguments as isic_conv2d_igemm_bf16; ..._supported() says whether a fused kernel exists for the
+ * shape (3x3, stride 1, pad 1, Cin >= 128, Cout % 128 == 0, W <= 63) -- otherwise the caller runs the unfused sequence. */
+size_t isic_conv2d_dgrad_bnbwd_supported(int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int Kh, int Kw,
+                                      int up, int down, int pad);
+int isic_conv2d_dgrad_bnbwd_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int Hin, int Win, int Cin,
+                                 int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad,
+                                 const uint16_t* addend, const uint8_t* relu_mask, const uint16_t* y_raw, double* sum_dz,
+                                 double* sum_dzy, int stat_slots, void* stream);
+int isic_bn_bwd_finalize(const double* sum_dz, const double* sum_dzy, int nslots, int C, const float* mean,
+                         const float* rstd, double* dgamma, double* dbeta, void* stream);
 /* Stem: 7x7/2 pad 3, 3->64, on NHWC input with C padded to 4.  w_stem is
  * [64][7][8][4] bf16 (kw, ci zero padded) made by isic_conv_stem_pack_bf16 from the
  * fp32 [64][7][7][3] parameter; the weight gradient accumulates (atomics) into

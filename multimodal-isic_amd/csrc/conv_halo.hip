@@ -45,8 +45,10 @@ struct HaloArgs {
   const unsigned short* w;       // [Cout][3][3][Cin]
   unsigned short* out;
   const unsigned short* addend;
-  double* stat_sum;
-  double* stat_sumsq;
+  double* stat_sum;              // STATS 1: sum of the outputs;  STATS 2: sum of dz
+  double* stat_sumsq;            // STATS 1: sum of squares;      STATS 2: sum of dz * y
+  const unsigned char* relu_mask;   // STATS 2: [M][Cout/8], bit c of a byte = ReLU mask of channel 8g + c (isic_bn_apply_mask_bf16)
+  const unsigned short* yraw;       // STATS 2: [M][Cout] the pre-BatchNorm activation of the layer whose gradient this is
   int stat_slots;
   int H, W, Cin, Cout, M;        // M = N*H*W
   int mtiles, nslices, groups;   // ceil(M/256), Cout/128, blocks per slice
@@ -80,8 +82,14 @@ __device__ __forceinline__ float halo_row16_sum(float v) {               // sum 
 }
 
 // LDS map (bytes): [0, 2*PB) two patch buffers (PB = prows*128) | 3 weight stages | 128 B zeros | 1 KB DMA scratch |
-// 256 floats of statistics
-template <bool STATS, bool ADDEND>
+// 256 floats of statistics (STATS 2: 8 waves x 128 floats)
+//
+// STATS: 0 none; 1 forward -- BatchNorm sum / sum of squares of the rounded outputs; 2 DATA GRADIENT FEEDING A
+// BatchNorm(+ReLU) BACKWARD -- the output g (+ addend) is the gradient of a ReLU(BatchNorm(y)) activation: the epilogue
+// applies the ReLU mask (1 bit per value, written by the forward), stores dz = mask ? g : 0 and accumulates the two
+// sums BatchNorm's backward needs, sum dz and sum dz * y, per channel -- the separate reduction pass over (g, y) and,
+// for a block's last BatchNorm, the materialised residual gradient (= dz) disappear.
+template <int STATS, bool ADDEND>
 __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -167,7 +175,8 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
   } else {
   // ===================================================================== MFMA waves
   if (tid < 8) reinterpret_cast<u32x4*>(smem + off_zero)[tid] = (u32x4){0u, 0u, 0u, 0u};   // 128 B of zeros
-  if (STATS && tid < 256) stats_lds[tid] = 0.f;
+  if (STATS == 1 && tid < 256) stats_lds[tid] = 0.f;
+  if (STATS == 2 && tid < 512) { stats_lds[tid] = 0.f; stats_lds[tid + 512] = 0.f; }   // 8 waves x 2 x 64
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // ordered before the first barrier of the K loop
 
   const int fr = lane & 15, fg = lane >> 4;
@@ -242,6 +251,81 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
     //      Every addend load is issued before the first store (vmcnt counts loads and stores in order: a load behind
     //      a store would wait for the store's round trip), and nothing behind the stores waits on vmcnt.
     const unsigned chan = (unsigned)(n0 + wn * 64 + fg * 8);
+    if constexpr (STATS == 2) {
+      // one pixel tile i at a time, so that addend + y + results fit beside the accumulators and the running sums; the
+      // loads of tile i + 1 are issued BEFORE the stores of tile i (a load behind a store waits for its round trip)
+      float s8[2][8], q8[2][8];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { s8[t][c] = 0.f; q8[t][c] = 0.f; }
+      u32x4 ad[2], yv[2], res[2];
+      unsigned mb[2];
+      auto load_tile = [&](int i) {
+        const int m = m0 + wm * 64 + i * 16 + fr;
+        const unsigned off = (unsigned)(m < a.M ? m : 0) * (unsigned)a.Cout + chan;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          if (ADDEND) ad[t] = *reinterpret_cast<const u32x4*>(a.addend + off + t * 32);
+          yv[t] = *reinterpret_cast<const u32x4*>(a.yraw + off + t * 32);
+          mb[t] = a.relu_mask[(off + t * 32) >> 3];
+        }
+      };
+      load_tile(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + fr;
+        const bool valid = m < a.M;
+        const unsigned off = (unsigned)(valid ? m : 0) * (unsigned)a.Cout + chan;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const unsigned bits = valid ? mb[t] : 0u;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            f32x4 c = acc[i][2 * t + h];
+            if (ADDEND) {
+              const unsigned lo = ad[t][2 * h], hi = ad[t][2 * h + 1];
+              c[0] += __uint_as_float(lo << 16);
+              c[1] += __uint_as_float(lo & 0xFFFF0000u);
+              c[2] += __uint_as_float(hi << 16);
+              c[3] += __uint_as_float(hi & 0xFFFF0000u);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c[e] = ((bits >> (4 * h + e)) & 1u) ? c[e] : 0.f;
+            const unsigned w0 = halo_pack2(c[0], c[1]), w1 = halo_pack2(c[2], c[3]);
+            res[t][2 * h] = w0;
+            res[t][2 * h + 1] = w1;
+            const unsigned ylo = yv[t][2 * h], yhi = yv[t][2 * h + 1];
+            const float r0 = __uint_as_float(w0 << 16), r1 = __uint_as_float(w0 & 0xFFFF0000u);       // the ROUNDED dz
+            const float r2 = __uint_as_float(w1 << 16), r3 = __uint_as_float(w1 & 0xFFFF0000u);
+            s8[t][4 * h + 0] += r0; q8[t][4 * h + 0] += r0 * __uint_as_float(ylo << 16);
+            s8[t][4 * h + 1] += r1; q8[t][4 * h + 1] += r1 * __uint_as_float(ylo & 0xFFFF0000u);
+            s8[t][4 * h + 2] += r2; q8[t][4 * h + 2] += r2 * __uint_as_float(yhi << 16);
+            s8[t][4 * h + 3] += r3; q8[t][4 * h + 3] += r3 * __uint_as_float(yhi & 0xFFFF0000u);
+          }
+        }
+        if (i + 1 < 4) load_tile(i + 1);                     // before this tile's stores
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          if (valid) __builtin_nontemporal_store(res[t], reinterpret_cast<u32x4*>(a.out + off + t * 32));
+      }
+      // DETERMINISTIC sums (they feed back into the gradient chain, which amplifies any run-to-run difference): each
+      // wave adds into its OWN 2 x 64 LDS floats, without atomics, tile after tile; the block's flush adds the four
+      // waves of a channel half in a fixed order
+      lds_float* sp = stats_lds + wave * 128 + lane;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float mine = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float sv = halo_row16_sum(s8[t][c]), qv = halo_row16_sum(q8[t][c]);
+          mine = fr == c ? sv : mine;
+          mine = fr == 8 + c ? qv : mine;
+        }
+        sp[t * 64] += mine;
+      }
+      continue;
+    }
     u32x4 ad[4][2];
     if (ADDEND) {
 #pragma unroll
@@ -253,7 +337,7 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
       }
     }
     float s8[2][8], q8[2][8];
-    if (STATS) {
+    if (STATS == 1) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -280,7 +364,7 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
           const unsigned w0 = halo_pack2(c[0], c[1]), w1 = halo_pack2(c[2], c[3]);
           v[2 * h] = w0;
           v[2 * h + 1] = w1;
-          if (STATS && valid) {                          // statistics of the ROUNDED outputs
+          if (STATS == 1 && valid) {                     // statistics of the ROUNDED outputs
             const float r0 = __uint_as_float(w0 << 16), r1 = __uint_as_float(w0 & 0xFFFF0000u);
             const float r2 = __uint_as_float(w1 << 16), r3 = __uint_as_float(w1 & 0xFFFF0000u);
             s8[t][4 * h + 0] += r0; q8[t][4 * h + 0] += r0 * r0;
@@ -292,7 +376,7 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
         if (valid) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.out + off + t * 32));
       }
     }
-    if (STATS) {
+    if (STATS == 1) {
       // lanes of one fg group (a DPP row of 16) hold the same 8 channels for 16 different pixels: every lane ends with
       // the row totals of the 16 values (8 sums, 8 sums of squares) of a channel group, and lane fr contributes value
       // #fr -- ONE 64-lane LDS atomic per channel group instead of 16 four-lane ones; the four wm waves of a channel
@@ -315,22 +399,33 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
   }
   }   // MFMA waves
 
-  if (STATS) {
+  if (STATS != 0) {
     lds_barrier();                                       // all sixteen waves: every tile's partial sums are in LDS
     if (tid < 256) {
       const size_t slot = (size_t)(blockIdx.x % a.stat_slots) * a.Cout + n0 + (tid & 127);
-      atomicAdd((tid < 128 ? a.stat_sum : a.stat_sumsq) + slot, (double)stats_lds[tid]);
+      float v;
+      if (STATS == 2) {
+        // channel c of the slice = wn*64 + t*32 + fg*8 + e lives in lane fg*16 + e (+ 8 for the second sum) of the
+        // slots of waves wm*2 + wn, wm = 0..3
+        const int c = tid & 127, l = ((c >> 3) & 3) * 16 + (c & 7) + (tid < 128 ? 0 : 8), t = (c >> 5) & 1, wn_ = c >> 6;
+        v = 0.f;
+#pragma unroll
+        for (int wm_ = 0; wm_ < 4; ++wm_) v += stats_lds[(wm_ * 2 + wn_) * 128 + t * 64 + l];
+      } else {
+        v = stats_lds[tid];
+      }
+      atomicAdd((tid < 128 ? a.stat_sum : a.stat_sumsq) + slot, (double)v);
     }
   }
 }
 
-template <bool STATS, bool ADDEND>
+template <int STATS, bool ADDEND>
 int launch_halo(const HaloArgs& a, int grid, int lds, hipStream_t stream) {
   static std::once_flag once;
   static hipError_t attr_rc = hipSuccess;
   std::call_once(once, [] {
     attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<STATS, ADDEND>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MAX_PROWS * 128 + NWST * WSTAGE + 2176);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MAX_PROWS * 128 + NWST * WSTAGE + 2176 + 3072);
   });
   if (attr_rc != hipSuccess) return ISIC_ERR_LAUNCH;
   hipLaunchKernelGGL((conv_halo_kernel<STATS, ADDEND>), dim3(grid), dim3(1024), lds, stream, a);
@@ -348,7 +443,7 @@ bool isic_conv_halo_supported(int N, int H, int W, int Cin, int Cout) {
 
 int isic_conv_halo_launch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int H, int W, int Cin, int Cout,
                           const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots,
-                          hipStream_t stream) {
+                          const uint8_t* relu_mask, const uint16_t* yraw, hipStream_t stream) {
   if (!isic_conv_halo_supported(N, H, W, Cin, Cout)) return ISIC_ERR_UNSUPPORTED;
   static int cus = 0;
   if (cus == 0) {
@@ -361,6 +456,7 @@ int isic_conv_halo_launch(const uint16_t* in, const uint16_t* w, uint16_t* out, 
   HaloArgs a;
   a.in = in; a.w = w; a.out = out; a.addend = addend;
   a.stat_sum = stat_sum; a.stat_sumsq = stat_sumsq; a.stat_slots = stat_slots > 0 ? stat_slots : 1;
+  a.relu_mask = relu_mask; a.yraw = yraw;
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.M = N * H * W;
   a.mtiles = ceil_div(a.M, HM);
   a.nslices = Cout / HN;
@@ -372,10 +468,14 @@ int isic_conv_halo_launch(const uint16_t* in, const uint16_t* w, uint16_t* out, 
   a.prows = ceil_div(HM + 2 * W + 2, 8) * 8;
   a.magic_hw = ((1ULL << 40) / (unsigned long long)(H * W)) + 1;
   a.magic_w = ((1ULL << 40) / (unsigned long long)W) + 1;
-  const int lds = 2 * a.prows * 128 + NWST * WSTAGE + 2176;
+  const int lds = 2 * a.prows * 128 + NWST * WSTAGE + 2176 + 3072;     // statistics: 1 KB (forward) or 4 KB (STATS 2)
   const int grid = a.groups * a.nslices;
+  if (relu_mask || yraw) {                                 // data gradient feeding a BatchNorm backward (STATS 2)
+    if (!relu_mask || !yraw || !stat_sum || !stat_sumsq) return ISIC_ERR_BAD_ARG;
+    return addend ? launch_halo<2, true>(a, grid, lds, stream) : launch_halo<2, false>(a, grid, lds, stream);
+  }
   if (stat_sum && addend) return ISIC_ERR_UNSUPPORTED;
-  if (stat_sum) return launch_halo<true, false>(a, grid, lds, stream);
-  if (addend) return launch_halo<false, true>(a, grid, lds, stream);
-  return launch_halo<false, false>(a, grid, lds, stream);
+  if (stat_sum) return launch_halo<1, false>(a, grid, lds, stream);
+  if (addend) return launch_halo<0, true>(a, grid, lds, stream);
+  return launch_halo<0, false>(a, grid, lds, stream);
 }

@@ -409,7 +409,8 @@ int isic_conv3x3_c64_launch(int variant, const uint16_t* in, const uint16_t* w, 
                             hipStream_t stream);
 bool isic_conv_halo_supported(int N, int H, int W, int Cin, int Cout);
 int isic_conv_halo_launch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int H, int W, int Cin, int Cout,
-                          const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots,
+                          const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots, const uint8_t* relu_mask,
+                          const uint16_t* yraw,
                           hipStream_t stream);
 int isic_conv_pgemm_launch(const isic_conv::ConvArgsN& classes, hipStream_t stream);
 
@@ -469,7 +470,7 @@ int conv2d_dispatch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N,
   if (same3x3 && cv.halo != 1 && !(stat_sum && addend) && isic_conv_halo_supported(N, Hin, Win, Cin, Cout) &&
       (cv.halo == 2 || Cin >= 128)) {
     const int rc = isic_conv_halo_launch(in, w, out, N, Hin, Win, Cin, Cout, addend, stat_sum, stat_sumsq, stat_slots,
-                                         as_stream(stream));
+                                         nullptr, nullptr, as_stream(stream));
     return rc != ISIC_OK ? rc : isic_launch_status();
   }
   ConvArgs a;
@@ -550,6 +551,25 @@ int isic_conv_weight_prep_bf16(const float* w_krsc, uint16_t* w_fwd, uint16_t* w
   hipLaunchKernelGGL(weight_prep_kernel, dim3((int)grid), dim3(256), 0, as_stream(stream), w_krsc, w_fwd, w_dgrad, O, I,
                      Kh, Kw);
   return isic_launch_status();
+}
+
+// Data gradient of a 3x3 / stride-1 convolution whose OUTPUT is the gradient of a ReLU(BatchNorm(y)) activation (+ an
+// optional residual-gradient addend): see conv_halo.hip, STATS 2.  Geometry arguments as isic_conv2d_igemm_bf16.
+size_t isic_conv2d_dgrad_bnbwd_supported(int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int Kh, int Kw,
+                                      int up, int down, int pad) {
+  const bool same3x3 = Kh == 3 && Kw == 3 && up == 1 && down == 1 && pad == 1 && Hin == Hout && Win == Wout;
+  return same3x3 && N > 0 && Cin >= 128 && Cout % 8 == 0 && isic_conv_halo_supported(N, Hin, Win, Cin, Cout) ? 1 : 0;
+}
+
+int isic_conv2d_dgrad_bnbwd_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int Hin, int Win, int Cin,
+                                 int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad,
+                                 const uint16_t* addend, const uint8_t* relu_mask, const uint16_t* y_raw, double* sum_dz,
+                                 double* sum_dzy, int stat_slots, void* stream) {
+  ISIC_CHECK_ARG(in && w && out && relu_mask && y_raw && sum_dz && sum_dzy && stat_slots > 0);
+  if (!isic_conv2d_dgrad_bnbwd_supported(N, Hin, Win, Cin, Hout, Wout, Cout, Kh, Kw, up, down, pad)) return ISIC_ERR_UNSUPPORTED;
+  const int rc = isic_conv_halo_launch(in, w, out, N, Hin, Win, Cin, Cout, addend, sum_dz, sum_dzy, stat_slots, relu_mask,
+                                       y_raw, as_stream(stream));
+  return rc != ISIC_OK ? rc : isic_launch_status();
 }
 
 }  // extern "C"

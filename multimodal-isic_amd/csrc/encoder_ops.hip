@@ -80,6 +80,19 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sum, const double*
   }
 }
 
+// dbeta = sum dz, dgamma = sum dz * xhat = rstd * (sum dz*y - mean * sum dz), from the per-slot partial sums a data-gradient
+// convolution accumulated in its epilogue (conv_halo.hip STATS 2); fp64 throughout
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ s_dz, const double* __restrict__ s_dzy, int nslots, int C,
+                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                       double* __restrict__ dgamma, double* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int s = 0; s < nslots; ++s) { a += s_dz[(size_t)s * C + c]; b += s_dzy[(size_t)s * C + c]; }
+  dbeta[c] = a;
+  dgamma[c] = (double)rstd[c] * (b - (double)mean[c] * a);
+}
+
 __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ rm, const float* __restrict__ rv, float eps, int C,
                                       float* __restrict__ scale, float* __restrict__ shift) {
@@ -546,6 +559,14 @@ int isic_bn_finalize(const double* sum, const double* sumsq, int nslots, int64_t
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, as_stream(stream), sum, sumsq, nslots,
                      rows, C,
                      gamma, beta, eps, momentum, scale, shift, mean, rstd, running_mean, running_var);
+  return isic_launch_status();
+}
+
+int isic_bn_bwd_finalize(const double* sum_dz, const double* sum_dzy, int nslots, int C, const float* mean,
+                         const float* rstd, double* dgamma, double* dbeta, void* stream) {
+  ISIC_CHECK_ARG(sum_dz && sum_dzy && mean && rstd && dgamma && dbeta && nslots > 0 && C > 0);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, as_stream(stream), sum_dz, sum_dzy, nslots,
+                     C, mean, rstd, dgamma, dbeta);
   return isic_launch_status();
 }
 

@@ -170,6 +170,39 @@ class ResNet18Encoder(nn.Module):
              addend, None, None, 0)
         return dx
 
+    def _dgrad_bnbwd_ok(self, dy_shape, name, in_shape):
+        """Is there a fused kernel for `dgrad(dy) -> ReLU mask -> BatchNorm-backward sums` of this layer?"""
+        sp = self.specs[name]
+        N, H, W, C = in_shape
+        _, Ho, Wo, Co = dy_shape
+        return bool(call("isic_conv2d_dgrad_bnbwd_supported", N, Ho, Wo, Co, H, W, C, sp.k, sp.k, 1, sp.stride,
+                         sp.k - 1 - sp.pad))
+
+    def _conv_dgrad_bnbwd(self, dy, name, in_shape, mask, yraw, addend=None):
+        """dz = relu_mask ? dgrad(dy) (+ addend) : 0 and the per-slot sums (sum dz, sum dz * yraw) of the BatchNorm
+        whose output the convolution consumed -- its backward then needs no reduction pass (conv_halo.hip, STATS 2)."""
+        sp = self.specs[name]
+        N, H, W, C = in_shape
+        _, Ho, Wo, Co = dy.shape
+        _, wd = self._weights(name, True)
+        dz = _empty(in_shape, dy)
+        sums = self._zeros64((2, STAT_SLOTS, C), dy.device)
+        call("isic_conv2d_dgrad_bnbwd_bf16", dy, wd, dz, N, Ho, Wo, Co, H, W, C, sp.k, sp.k, 1, sp.stride, sp.k - 1 - sp.pad,
+             addend, mask, yraw, sums[0], sums[1], STAT_SLOTS)
+        return dz, sums
+
+    def _bn_bwd_from_sums(self, dz, c, st, name, sums):
+        """BatchNorm backward when dz (ReLU mask already applied) and its sums came out of the producing data gradient."""
+        mean, rstd = st[0], st[1]
+        N, H, W, C = c.shape
+        gamma, beta = self._get(name + ".weight"), self._get(name + ".bias")
+        acc = self._zeros64((2, C), c.device)
+        call("isic_bn_bwd_finalize", sums[0], sums[1], STAT_SLOTS, C, mean, rstd, acc[0], acc[1])
+        dx = _empty(c.shape, c)
+        call("isic_bn_bwd_apply_bf16", dz, c, None, mean, rstd, gamma.data, acc[0], acc[1], N * H * W, C, 0, None, None, dx,
+             None, self._grad_buffer(gamma), self._grad_buffer(beta))
+        return dx
+
     def _grad_buffer(self, p):
         if p.grad is None:
             p.grad = torch.zeros_like(p.data, memory_format=torch.preserve_format)
@@ -240,8 +273,9 @@ class ResNet18Encoder(nn.Module):
         st = self._bn_affine(c, name, acc)
         N, H, W, C = c.shape
         y = _empty(c.shape, c)
-        if relu and residual is not None and self.training:
-            # the backward passes need the ReLU mask of relu(bn(c) + residual): kept as 1 bit per element
+        if relu and self.training:
+            # the backward passes need the ReLU mask of relu(bn(c) [+ residual]): kept as 1 bit per element (with a
+            # residual it cannot be recomputed from c; without one it is what the fused data-gradient epilogue reads)
             mask = torch.empty((N * H * W * C) // 8, device=c.device, dtype=torch.uint8)
             call("isic_bn_apply_mask_bf16", c, st[2], st[3], residual, y, mask, N * H * W, C)
             return y, st + (mask,)
@@ -335,25 +369,46 @@ class ResNet18Encoder(nn.Module):
     def block_backward(self, g, pre, ds, saved):
         """Backward of ``block_forward``: ``g`` = d loss / d out (NHWC bf16).  Accumulates the block's parameter
         gradients into ``param.grad`` and returns (d loss / d x, names of the parameters whose gradients are final)."""
+        dx, names, _ = self.block_backward_fused(g, pre, ds, saved)
+        return dx, names
+
+    def block_backward_fused(self, g, pre, ds, saved, g_sums=None, prev=None):
+        """``block_backward`` with the BatchNorm-backward reductions folded into the data gradients that produce their
+        inputs, where a fused kernel exists (3x3 stride-1 layers with >= 128 channels):
+          * ``g_sums`` given: ``g`` is ALREADY dz of bn2 (ReLU mask applied by the producer) with its (sum dz, sum dz*c2);
+          * ``prev`` = ``saved`` of the preceding block: the data gradient of conv1 then applies THAT block's output
+            mask and returns dz of its bn2 together with the sums (third return value, else None)."""
         x, c1, a1, st1, c2, out, st2, cd, std = saved
-        dc2, dres = self._bn_bwd(g, c2, out, st2, f"{pre}.bn2", True, True)
+        if g_sums is not None:
+            dc2, dres = self._bn_bwd_from_sums(g, c2, st2, f"{pre}.bn2", g_sums), g      # the residual gradient IS dz
+        else:
+            dc2, dres = self._bn_bwd(g, c2, out, st2, f"{pre}.bn2", True, True)
         self._conv_wgrad(a1, dc2, f"{pre}.conv2")
-        da1 = self._conv_dgrad(dc2, f"{pre}.conv2", tuple(a1.shape))
-        del dc2
-        dc1, _ = self._bn_bwd(da1, c1, a1, st1, f"{pre}.bn1", True, False, mask_from_x=True)
-        del da1
+        if len(st1) > 4 and self._dgrad_bnbwd_ok(dc2.shape, f"{pre}.conv2", tuple(a1.shape)):
+            dz1, sums1 = self._conv_dgrad_bnbwd(dc2, f"{pre}.conv2", tuple(a1.shape), st1[4], c1)
+            del dc2
+            dc1 = self._bn_bwd_from_sums(dz1, c1, st1, f"{pre}.bn1", sums1)
+            del dz1
+        else:
+            da1 = self._conv_dgrad(dc2, f"{pre}.conv2", tuple(a1.shape))
+            del dc2
+            dc1, _ = self._bn_bwd(da1, c1, a1, st1, f"{pre}.bn1", True, False, mask_from_x=True)
+            del da1
         self._conv_wgrad(x, dc1, f"{pre}.conv1")
         names = [f"{pre}.conv2.weight", f"{pre}.bn2.weight", f"{pre}.bn2.bias", f"{pre}.conv1.weight",
                  f"{pre}.bn1.weight", f"{pre}.bn1.bias"]
+        dx_sums = None
         if ds:
             dcd, _ = self._bn_bwd(dres, cd, None, std, f"{pre}.downsample.1", False, False)
             self._conv_wgrad(x, dcd, f"{pre}.downsample.0")
             dx2 = self._conv_dgrad(dcd, f"{pre}.downsample.0", tuple(x.shape))
             dx = self._conv_dgrad(dc1, f"{pre}.conv1", tuple(x.shape), addend=dx2)
             names += [f"{pre}.downsample.0.weight", f"{pre}.downsample.1.weight", f"{pre}.downsample.1.bias"]
+        elif prev is not None and len(prev[6]) > 4 and self._dgrad_bnbwd_ok(dc1.shape, f"{pre}.conv1", tuple(x.shape)):
+            dx, dx_sums = self._conv_dgrad_bnbwd(dc1, f"{pre}.conv1", tuple(x.shape), prev[6][4], prev[4], addend=dres)
         else:
             dx = self._conv_dgrad(dc1, f"{pre}.conv1", tuple(x.shape), addend=dres)   # + identity gradient
-        return dx, names
+        return dx, names, dx_sums
 
     def run_forward(self, images, save):
         """Returns (features[N,512] fp32, tape).  ``save=False`` drops everything not
@@ -433,8 +488,11 @@ class ResNet18Encoder(nn.Module):
         self._arena_reset(dfeat.device)
         g = torch.empty((N, Hf, Wf, Cf), device=dfeat.device, dtype=_BF16)
         call("isic_avgpool_bwd_bf16", dfeat.float().contiguous(), g, N, Hf * Wf, Cf)
-        for (pre, ds), saved in zip(reversed(self.blocks), reversed(tape["blocks"])):
-            g, names = self.block_backward(g, pre, ds, saved)
+        g_sums = None
+        for bi in range(len(self.blocks) - 1, -1, -1):
+            pre, ds = self.blocks[bi]
+            prev = tape["blocks"][bi - 1] if bi > 0 else None
+            g, names, g_sums = self.block_backward_fused(g, pre, ds, tape["blocks"][bi], g_sums=g_sums, prev=prev)
             self._fire(names)
         c, st0, am, csel, yshape = tape["stem"]
         N, Ho, Wo, _ = yshape

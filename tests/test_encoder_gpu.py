@@ -267,6 +267,76 @@ def test_conv_pgemm_kernel(case):
         bf16_close(from_nhwc(got), F.conv2d(xr, wr, None, s, p), f"pgemm fwd {case}")
 
 
+@pytest.mark.parametrize("case", [(3, 10, 10, 128, 128), (70, 28, 28, 128, 128), (33, 14, 14, 256, 256), (65, 7, 7, 512, 512),
+                                  (5, 9, 11, 128, 256)])
+@pytest.mark.parametrize("with_addend", [False, True])
+def test_dgrad_with_fused_relu_mask_and_bn_backward_sums(case, with_addend):
+    """isic_conv2d_dgrad_bnbwd_bf16 == isic_conv2d_igemm_bf16 (data gradient, + addend) followed by the ReLU mask, bit for
+    bit, and its per-channel sums == fp64 sums of (dz, dz * y) over the stored tensor; isic_bn_bwd_finalize turns them
+    into the dgamma / dbeta that isic_bn_bwd_reduce_mask_bf16 computes from the unfused tensors."""
+    from isic_hip.lib import call
+    N, H, W, Cdy, Cg = case                       # dy has Cdy channels, the gradient g (and y, mask) Cg
+    g = torch.Generator().manual_seed(17)
+    dy = torch.randn(N, H, W, Cdy, generator=g).to(DEV).to(BF)
+    w = torch.randn(Cdy, Cg, 3, 3, generator=g) / np.sqrt(Cdy * 9)       # forward weight [Cout=Cdy][Cin=Cg]
+    wf = torch.empty(Cdy * Cg * 9, device=DEV, dtype=BF)
+    wd = torch.empty_like(wf)
+    call("isic_conv_weight_prep_bf16", krsc(w), wf, wd, Cdy, Cg, 3, 3)
+    add = torch.randn(N, H, W, Cg, generator=g).to(DEV).to(BF) if with_addend else None
+    y = (torch.randn(N, H, W, Cg, generator=g) * 1.5 + 0.3).to(DEV).to(BF)
+    bits = (torch.rand(N * H * W * Cg, generator=g) > 0.4)
+    mask = (bits.view(-1, 8).to(torch.int32) << torch.arange(8, dtype=torch.int32)).sum(1).to(torch.uint8).to(DEV)
+    assert call("isic_conv2d_dgrad_bnbwd_supported", N, H, W, Cdy, H, W, Cg, 3, 3, 1, 1, 1) == 1
+    ref = torch.empty(N, H, W, Cg, device=DEV, dtype=BF)
+    call("isic_conv2d_igemm_bf16", dy, wd, ref, N, H, W, Cdy, H, W, Cg, 3, 3, 1, 1, 1, add, None, None, 0)
+    ref = torch.where(bits.view(N, H, W, Cg).to(DEV), ref, torch.zeros_like(ref))
+    slots = 32
+    sums = torch.zeros(2, slots, Cg, device=DEV, dtype=torch.float64)
+    dz = torch.full((N, H, W, Cg), float("nan"), device=DEV, dtype=BF)
+    call("isic_conv2d_dgrad_bnbwd_bf16", dy, wd, dz, N, H, W, Cdy, H, W, Cg, 3, 3, 1, 1, 1, add, mask, y, sums[0], sums[1], slots)
+    torch.cuda.synchronize()
+    assert torch.equal(dz.view(torch.int16), ref.view(torch.int16)), f"{int((dz != ref).sum())} values differ"
+    d, yy = dz.double().view(-1, Cg), y.double().view(-1, Cg)
+    assert_close(sums[0].sum(0).cpu(), d.sum(0).cpu(), rtol=2e-5, atol=2e-3, what="sum dz")
+    assert_close(sums[1].sum(0).cpu(), (d * yy).sum(0).cpu(), rtol=2e-5, atol=5e-3, what="sum dz*y")
+    mean = (torch.randn(Cg, generator=g) * 0.3).to(DEV)
+    rstd = (torch.rand(Cg, generator=g) + 0.5).to(DEV)
+    fin = torch.zeros(2, Cg, device=DEV, dtype=torch.float64)
+    call("isic_bn_bwd_finalize", sums[0], sums[1], slots, Cg, mean, rstd, fin[0], fin[1])
+    red = torch.zeros(2, Cg, device=DEV, dtype=torch.float64)
+    gfull = torch.empty(N, H, W, Cg, device=DEV, dtype=BF)
+    call("isic_conv2d_igemm_bf16", dy, wd, gfull, N, H, W, Cdy, H, W, Cg, 3, 3, 1, 1, 1, add, None, None, 0)
+    call("isic_bn_bwd_reduce_mask_bf16", gfull, y, mask, mean, rstd, N * H * W, Cg, red[0], red[1])
+    scale = float(d.abs().sum(0).max().cpu()) + 1.0
+    assert_close(fin.cpu(), red.cpu(), rtol=1e-4, atol=2e-5 * scale * 4, what="dgamma / dbeta from the fused sums")
+
+
+def test_encoder_backward_with_and_without_fused_bn_reductions(monkeypatch):
+    """The whole ResNet-18 backward with the BatchNorm reductions folded into the data gradients (stages 2-4) against
+    the same backward with every reduction run as its own pass: the parameter gradients agree to bf16 noise."""
+    from isic_hip.encoder import ResNet18Encoder
+    torch.manual_seed(3)
+    enc = ResNet18Encoder().to(DEV).train()
+    x = torch.randn(6, 3, 64, 64, generator=torch.Generator().manual_seed(4)).to(DEV)
+    gfeat = torch.randn(6, 512, generator=torch.Generator().manual_seed(5)).to(DEV)
+    state = {k: v.clone() for k, v in enc.state_dict().items()}
+
+    def grads(fused):
+        enc.load_state_dict(state)
+        for p in enc.parameters():
+            p.grad = None
+        if not fused:
+            monkeypatch.setattr(ResNet18Encoder, "_dgrad_bnbwd_ok", lambda self, *a: False)
+        feat, tape = enc.run_forward(x, save=True)
+        enc.run_backward(tape, gfeat)
+        torch.cuda.synchronize()
+        monkeypatch.undo()
+        return {k: p.grad.detach().float().clone() for k, p in enc.named_parameters()}
+    a, b = grads(True), grads(False)
+    worst = max(float((a[k] - b[k]).abs().max() / (b[k].abs().max() + 1e-12)) for k in a)
+    assert worst <= 2e-2, worst                                  # different rounding points of dz sums; bf16 chain below
+
+
 @pytest.mark.parametrize("C", [64, 128])
 @pytest.mark.parametrize("shape", [(2, 13, 37), (40, 56, 56), (150, 56, 56), (37, 28, 40)])
 def test_conv_wgrad_all_taps_kernels(shape, C):
