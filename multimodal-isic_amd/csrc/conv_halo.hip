@@ -28,6 +28,7 @@
 // The reference has no convolution kernel of its own (its encoder is an un-vendored ConvMAE run through torch,
 // save_latent.py:42-60); BASELINE.json configs[1] names ResNet-18 (SURVEY.md 8d layer table).
 #include <mutex>
+#include <type_traits>
 
 #include "common.h"
 
@@ -252,34 +253,47 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
     //      a store would wait for the store's round trip), and nothing behind the stores waits on vmcnt.
     const unsigned chan = (unsigned)(n0 + wn * 64 + fg * 8);
     if constexpr (STATS == 2) {
-      // one pixel tile i at a time, so that addend + y + results fit beside the accumulators and the running sums; the
-      // loads of tile i + 1 are issued BEFORE the stores of tile i (a load behind a store waits for its round trip)
-      float s8[2][8], q8[2][8];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) { s8[t][c] = 0.f; q8[t][c] = 0.f; }
-      u32x4 ad[2], yv[2], res[2];
-      unsigned mb[2];
-      auto load_tile = [&](int i) {
+      // One pixel tile i at a time with TWO tiles' operands (addend, y, mask byte) in flight: the loads of tile i + 2
+      // are issued before the stores of tile i (a load behind a store would wait for the store's round trip).  No sums
+      // are carried across tiles in registers -- that is what makes room for the second set of operands: each tile's
+      // 16 values per lane are reduced over the DPP row at once and added to the wave's own LDS slots.
+      // DETERMINISTIC sums (they feed back into the gradient chain, which amplifies any run-to-run difference): no
+      // atomics, fixed order; the block's flush adds the four waves of a channel half in a fixed order.
+      u32x4 ad[2], yv[2][2];                                 // addend: one tile ahead; y and mask: two tiles ahead
+      unsigned mb[2][2];
+      // (the tile index is a compile-time constant INSIDE the lambda: with a run-time parameter the operand arrays are
+      //  indexed dynamically before inlining and end up in scratch memory)
+      auto load_tile = [&](auto IC) {
+        constexpr int i = decltype(IC)::value;
         const int m = m0 + wm * 64 + i * 16 + fr;
         const unsigned off = (unsigned)(m < a.M ? m : 0) * (unsigned)a.Cout + chan;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          if (ADDEND) ad[t] = *reinterpret_cast<const u32x4*>(a.addend + off + t * 32);
-          yv[t] = *reinterpret_cast<const u32x4*>(a.yraw + off + t * 32);
-          mb[t] = a.relu_mask[(off + t * 32) >> 3];
+          yv[i & 1][t] = *reinterpret_cast<const u32x4*>(a.yraw + off + t * 32);
+          mb[i & 1][t] = a.relu_mask[(off + t * 32) >> 3];
         }
       };
-      load_tile(0);
+      auto load_addend = [&](int i) {
+        const int m = m0 + wm * 64 + i * 16 + fr;
+        const unsigned off = (unsigned)(m < a.M ? m : 0) * (unsigned)a.Cout + chan;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) ad[t] = *reinterpret_cast<const u32x4*>(a.addend + off + t * 32);
+      };
+      if (ADDEND) load_addend(0);
+      load_tile(std::integral_constant<int, 0>{});
+      load_tile(std::integral_constant<int, 1>{});
+      lds_float* sp = stats_lds + wave * 128 + lane;
+      float tot[2] = {0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + i * 16 + fr;
         const bool valid = m < a.M;
         const unsigned off = (unsigned)(valid ? m : 0) * (unsigned)a.Cout + chan;
+        u32x4 res[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const unsigned bits = valid ? mb[t] : 0u;
+          const unsigned bits = valid ? mb[i & 1][t] : 0u;
+          float s8[8], q8[8];
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             f32x4 c = acc[i][2 * t + h];
@@ -295,35 +309,35 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
             const unsigned w0 = halo_pack2(c[0], c[1]), w1 = halo_pack2(c[2], c[3]);
             res[t][2 * h] = w0;
             res[t][2 * h + 1] = w1;
-            const unsigned ylo = yv[t][2 * h], yhi = yv[t][2 * h + 1];
+            const unsigned ylo = yv[i & 1][t][2 * h], yhi = yv[i & 1][t][2 * h + 1];
             const float r0 = __uint_as_float(w0 << 16), r1 = __uint_as_float(w0 & 0xFFFF0000u);       // the ROUNDED dz
             const float r2 = __uint_as_float(w1 << 16), r3 = __uint_as_float(w1 & 0xFFFF0000u);
-            s8[t][4 * h + 0] += r0; q8[t][4 * h + 0] += r0 * __uint_as_float(ylo << 16);
-            s8[t][4 * h + 1] += r1; q8[t][4 * h + 1] += r1 * __uint_as_float(ylo & 0xFFFF0000u);
-            s8[t][4 * h + 2] += r2; q8[t][4 * h + 2] += r2 * __uint_as_float(yhi << 16);
-            s8[t][4 * h + 3] += r3; q8[t][4 * h + 3] += r3 * __uint_as_float(yhi & 0xFFFF0000u);
+            s8[4 * h + 0] = r0; q8[4 * h + 0] = r0 * __uint_as_float(ylo << 16);
+            s8[4 * h + 1] = r1; q8[4 * h + 1] = r1 * __uint_as_float(ylo & 0xFFFF0000u);
+            s8[4 * h + 2] = r2; q8[4 * h + 2] = r2 * __uint_as_float(yhi << 16);
+            s8[4 * h + 3] = r3; q8[4 * h + 3] = r3 * __uint_as_float(yhi & 0xFFFF0000u);
           }
+          float mine = 0.f;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const float sv = halo_row16_sum(s8[c]), qv = halo_row16_sum(q8[c]);
+            mine = fr == c ? sv : mine;
+            mine = fr == 8 + c ? qv : mine;
+          }
+          tot[t] += mine;                                    // fixed order i = 0..3
+          asm volatile("" : "+v"(tot[t]));                   // computed HERE: hipcc otherwise sinks all 128 partial sums
+                                                             // of a tile to its end -- and spills them
         }
-        if (i + 1 < 4) load_tile(i + 1);                     // before this tile's stores
+        if (ADDEND && i + 1 < 4) load_addend(i + 1);         // (every load of the epilogue is issued before a store it follows)
+        if (i == 0) load_tile(std::integral_constant<int, 2>{});      // before this tile's stores
+        if (i == 1) load_tile(std::integral_constant<int, 3>{});
 #pragma unroll
         for (int t = 0; t < 2; ++t)
           if (valid) __builtin_nontemporal_store(res[t], reinterpret_cast<u32x4*>(a.out + off + t * 32));
+        __builtin_amdgcn_sched_barrier(0);                   // one tile at a time: keeps the register footprint bounded
       }
-      // DETERMINISTIC sums (they feed back into the gradient chain, which amplifies any run-to-run difference): each
-      // wave adds into its OWN 2 x 64 LDS floats, without atomics, tile after tile; the block's flush adds the four
-      // waves of a channel half in a fixed order
-      lds_float* sp = stats_lds + wave * 128 + lane;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        float mine = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const float sv = halo_row16_sum(s8[t][c]), qv = halo_row16_sum(q8[t][c]);
-          mine = fr == c ? sv : mine;
-          mine = fr == 8 + c ? qv : mine;
-        }
-        sp[t * 64] += mine;
-      }
+      sp[0] += tot[0];
+      sp[64] += tot[1];
       continue;
     }
     u32x4 ad[4][2];
