@@ -257,6 +257,11 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(StemArgs a) {
 // written (3.3 GB at 2048 images) and this kernel read back.  A thread owns the 2x2 pixels (2a+dy, 2b+dx) of one
 // 8-channel group (pool_grad.h): 8 x 16 tile = 4 x 8 such blocks x 8 groups = 256 threads.  The raw loads of the NEXT
 // tile stay in registers while the current one is multiplied; the arithmetic happens when they are committed to LDS.
+// VALU-bound: ~1,650 vector instructions per thread and tile (max-pool routing: 9 compare / select / add per channel;
+// BatchNorm: ~8 per value; addressing) = 6.6 k cycles per tile and SIMD against 1 k of MFMA.  Measured and rejected:
+// a producer / consumer split (4 waves load + form dY with two tiles of operands in flight, 4 waves multiply: 2.7 ms
+// vs 2.15 ms -- one VALU wave per SIMD issues worse than two) and wave-uniform base + per-thread constant offsets with an
+// incremental tile cursor (2.11 ms: the address arithmetic was not the bulk of it).
 struct StemBnArgs {
   StemArgs s;                       // s.dy unused
   const unsigned short* y0;         // [N,Hout,Wout,64] stem convolution output
