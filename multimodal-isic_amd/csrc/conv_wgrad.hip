@@ -80,7 +80,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = KSPLIT ? 0 : (wave >> 1), wn = KSPLIT ? 0 : (wave & 1);
-  // blockIdx.x = ((tap * ci_tiles) + ci_t) * co_tiles + co_t   (tiles sharing a pixel range run together)
+  // blockIdx.x = ((tap * ci_tiles) + ci_t) * co_tiles + co_t   (tiles sharing a pixel range run together, spread over
+  // the 8 XCDs; pinning all tiles of a pixel range to ONE XCD was measured slower: 256/512-channel layers have 36-144
+  // tiles per range, more than an XCD runs at once, so they stop streaming in step -- l4 0.59 -> 0.88 ms)
   int bt = blockIdx.x;
   const int co_t = bt % a.co_tiles; bt /= a.co_tiles;
   const int ci_t = bt % a.ci_tiles;
