@@ -184,6 +184,7 @@ def run_mil(args, world, rank, dev):
     ddp.broadcast_parameters(flat.data)
     sync = ddp.GradSync(flat.grad, world_size=world)
     ddp.attach(model.encoder, flat, sync)
+    model.encoder.fuse_bn_backward = bool(args.bn_fusion)
 
     # synthetic ISIC-shaped data, resident in HBM (bf16 images as the dataset loader would hand them over)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -465,6 +466,8 @@ def main():
     ap.add_argument("--gnn-layers", type=int, default=3)
     ap.add_argument("--knn-k", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bn-fusion", action="store_true",
+                    help="mil: fold the BatchNorm-backward reductions of stages 2-4 into the data gradients (A/B; off by default)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     args = ap.parse_args()
 

@@ -85,6 +85,10 @@ class ResNet18Encoder(nn.Module):
         self._zeros_used = 0
         self._side = None             # second HIP stream: weight gradients run beside the data-gradient chain
         self.wgrad_stream = False     # opt-in (attribute, not an environment switch): see _side_stream
+        # BatchNorm-backward sums inside the producing data gradient (stages 2-4; conv_halo.hip STATS 2).  Same-box A/B at
+        # 2048 images: BatchNorm passes -1.0 ms, data gradients +0.75 ms per step -> +0.6 % bags/s, inside the run-to-run
+        # noise, while the convolution entry's roofline fraction drops 0.369 -> 0.352: off by default, kept as an option.
+        self.fuse_bn_backward = False
         self.grad_ready_hook = None   # callable(list_of_param_names) fired as gradients complete (DDP overlap)
 
     # parameters are registered under dotted torchvision names via nested holder modules
@@ -172,6 +176,8 @@ class ResNet18Encoder(nn.Module):
 
     def _dgrad_bnbwd_ok(self, dy_shape, name, in_shape):
         """Is there a fused kernel for `dgrad(dy) -> ReLU mask -> BatchNorm-backward sums` of this layer?"""
+        if not self.fuse_bn_backward:
+            return False
         sp = self.specs[name]
         N, H, W, C = in_shape
         _, Ho, Wo, Co = dy_shape

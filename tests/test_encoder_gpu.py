@@ -311,7 +311,7 @@ def test_dgrad_with_fused_relu_mask_and_bn_backward_sums(case, with_addend):
     assert_close(fin.cpu(), red.cpu(), rtol=1e-4, atol=2e-5 * scale * 4, what="dgamma / dbeta from the fused sums")
 
 
-def test_encoder_backward_with_and_without_fused_bn_reductions(monkeypatch):
+def test_encoder_backward_with_and_without_fused_bn_reductions():
     """The whole ResNet-18 backward with the BatchNorm reductions folded into the data gradients (stages 2-4) against
     the same backward with every reduction run as its own pass: the parameter gradients agree to bf16 noise."""
     from isic_hip.encoder import ResNet18Encoder
@@ -325,12 +325,10 @@ def test_encoder_backward_with_and_without_fused_bn_reductions(monkeypatch):
         enc.load_state_dict(state)
         for p in enc.parameters():
             p.grad = None
-        if not fused:
-            monkeypatch.setattr(ResNet18Encoder, "_dgrad_bnbwd_ok", lambda self, *a: False)
+        enc.fuse_bn_backward = fused
         feat, tape = enc.run_forward(x, save=True)
         enc.run_backward(tape, gfeat)
         torch.cuda.synchronize()
-        monkeypatch.undo()
         return {k: p.grad.detach().float().clone() for k, p in enc.named_parameters()}
     a, b = grads(True), grads(False)
     worst = max(float((a[k] - b[k]).abs().max() / (b[k].abs().max() + 1e-12)) for k in a)
