@@ -469,6 +469,10 @@ def main():
     ap.add_argument("--bn-fusion", action="store_true",
                     help="mil: fold the BatchNorm-backward reductions of stages 2-4 into the data gradients (A/B; off by default)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank REHEARSAL for a box with one GPU: every rank uses cuda:0 and the collectives run "
+                         "over gloo.  Exercises sharding, the bucketed gradient exchange fired by a real backward and the "
+                         "buffer averaging; the printed rate is NOT a scaling measurement (ranks share one GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -477,15 +481,22 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     line = (run_mil if args.config == "mil" else run_gnn)(args, world, rank, dev)
     if rank == 0:
         line["kernel_source_hash"] = kernel_source_hash()
+        if args.rehearse_on_one_gpu:
+            line["rehearsal"] = "all ranks on one GPU, gloo collectives: a functional check, not a scaling number"
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

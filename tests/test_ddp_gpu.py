@@ -109,3 +109,28 @@ def test_shard_gradients_sum_to_batched_gradients(kind):
         a, b = shard[k] / world, full[k]
         tol = 1e-5 * float(b.abs().max()) + 1e-8
         assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()), tol)
+
+
+def test_two_rank_rehearsal_of_the_bench_step_on_one_gpu(tmp_path):
+    """The whole multi-rank bench path -- rendezvous, per-rank sharding, the bucketed gradient exchange fired by the
+    real encoder backward, identical AdamW on every rank, buffer averaging, the MAX-over-ranks timing -- with two
+    processes that share cuda:0 and gloo collectives (`bench.py --rehearse-on-one-gpu`).  RCCL itself needs two GPUs."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2",
+           "--warmup", "1", "--bags-per-step", "2", "--patches", "4", "--image-size", "64", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_bags_per_step"] == 4
+    assert line["value"] > 0 and line["config"]["final_loss"] == line["config"]["final_loss"]      # finite, not NaN
+    assert "rehearsal" in line
