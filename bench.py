@@ -2,6 +2,7 @@
 
     python bench.py --gpus 1 --steps 8 --warmup 2                     # configs[1]: attention-MIL, ResNet-18 encoder
     python bench.py --config gnn --gpus 1 --steps 20 --warmup 5       # configs[3]: patch-graph GNN (05_train_gnns.py path)
+    python bench.py --config vit --gpus 1 --steps 10 --warmup 2       # configs[4]: frozen ViT-S/16 fp16 patch encoder (forward)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -37,6 +38,8 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROAR
 HBM_PEAK_GBS = 8000.0            # HBM3E spec, same guide (6.3 TB/s measured streaming)
 WORKLOAD_MIL = ("ISIC-shaped attention-MIL: 256 bags x 64x224x224 patches + 128-d radiomics, "
                 "ResNet-18 encoder, bf16 (BASELINE.json configs[1])")
+WORKLOAD_VIT = ("Frozen ViT-S/16 fp16 patch encoder of the full pipeline (BASELINE.json configs[4]): 224x224 images -> 196 x 384 "
+                "tokens; forward only, as the reference runs its encoder (save_latent.py:51-53)")
 WORKLOAD_GNN = ("Patch-graph GNN (05_train_gnns.py path): k-NN (k=8) graphs of 196 nodes on 768-d patch embeddings, "
                 "3-layer GCN F=128, 4-head attention pool (BASELINE.json configs[3])")
 
@@ -63,7 +66,10 @@ KERNEL_CLASSES = (
     ("graph", ("isic_spmm", "isic_gat", "isic_gcn_csr", "isic_knn", "isic_l2normalize", "isic_edge", "isic_fa",
                "isic_transformer", "isic_hetero")),
     ("attn_pool", ("isic_attn_pool",)),
-    ("gemm_f32", ("isic_gemm", "isic_colsum")),
+    ("gemm_f16", ("isic_gemm_f16",)),
+    ("vit_attention", ("isic_attention_f16",)),
+    ("vit_layernorm_patchify", ("isic_layernorm_f16", "isic_vit_patchify")),
+    ("gemm_f32", ("isic_gemm_f32", "isic_colsum")),
 )
 
 
@@ -105,7 +111,7 @@ class KernelTimer:
 
         lib.call = timed_call
         import isic_hip
-        for modname in ("encoder", "ops", "graph", "optim", "hetero"):
+        for modname in ("encoder", "ops", "graph", "optim", "hetero", "vit"):
             mod = getattr(isic_hip, modname, None)
             if mod is None:
                 try:
@@ -273,6 +279,68 @@ def cpu_baseline_mil(model, K, S, R, C, budget_s):
             "one_thread": {"value": v_one, "cores": 1,
                            "sample": f"{d_one} steps on bags of {k_one} patches, scaled by {k_one}/{K}"},
             "host_cpus": os.cpu_count()}
+
+
+# ----------------------------------------------------------------------------------------------- configs[4]: ViT encoder
+def run_vit(args, world, rank, dev):
+    """A "step" = the frozen encoder's forward over one batch of --images-per-step images (per GPU; ranks are independent
+    replicas: inference has no exchange step)."""
+    from isic_hip.vit import ViTSmallEncoder
+    n_img, S = args.images_per_step, args.image_size
+    torch.manual_seed(42)
+    enc = ViTSmallEncoder(img_size=S).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(99 + rank)
+    x = torch.randn(n_img, 3, S, S, device=dev, generator=gen)
+    timer = KernelTimer()
+    timer.install()
+
+    def step(i):
+        return enc.run_tokens(x).sum()
+
+    for i in range(2 + args.warmup):
+        step(i)
+    elapsed, host_s, _ = timed_region(step, args, world, dev, timer, ["isic_gemm_f16"], 2 + args.warmup)
+    gemm = timer.stop()
+    split = instrumented_pass(step, timer, dev, world, start=0)
+    if rank != 0:
+        return None
+    ms = sum(m for _n, _a, m in gemm)
+    fl = sum(2.0 * a[5] * a[6] * a[7] for _n, a, _m in gemm)          # (A, W, bias, residual, C, M, N, K, ...)
+    achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    line = base_line("images/sec (ViT-S/16 fp16 patch-encoder forward) @ 224x224", "images/s",
+                     world * n_img * args.steps / elapsed, world, args, elapsed, "f16")
+    line["scaling"] = "weak"
+    line["config"] = {"workload": WORKLOAD_VIT, "images_per_step_per_gpu": n_img, "image": f"3x{S}x{S}", "tokens": enc.tokens,
+                      "dim": enc.dim, "depth": enc.depth, "heads": enc.heads, "parallelism": f"replicas{world}",
+                      "host_enqueue_ms_per_step": host_s * 1e3 / args.steps,
+                      "whole_forward_algorithmic_tflops": enc.flops_per_image() * n_img * args.steps / elapsed / 1e12}
+    line["roofline"] = {
+        "bound": "mfma", "kernel": "C-ABI entry isic_gemm_f16 (every Linear of the encoder with its bias / GELU / residual "
+                                   "epilogue: 49 launches per forward)",
+        "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
+        "traffic": None, "launches": len(gemm), "avg_launch_ms": ms / max(len(gemm), 1),
+        "algorithmic_gflop_per_launch": fl / max(len(gemm), 1) / 1e9, "share_of_step_time": ms * 1e-3 / elapsed,
+        "measured": "HIP events inside the timed region",
+    }
+    line["kernel_time"] = split
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import vit as ovit
+        p = {k: v.detach().float().cpu() for k, v in enc.state_dict().items()}
+        threads = torch.get_num_threads()
+        nb = 8
+        xb = x[:nb].float().cpu()
+        with torch.no_grad():
+            ovit.forward_tokens(p, xb[:2])
+            t0 = time.perf_counter()
+            done = 0
+            while done < 6 and time.perf_counter() - t0 < args.cpu_budget_s:
+                ovit.forward_tokens(p, xb)
+                done += 1
+            dt = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": done * nb / dt, "unit": "images/s", "cores": threads, "kind": "port",
+                                "sample": f"{done} forward passes of {nb} images (oracle/vit.py, fp32, torch CPU, {threads} "
+                                          f"threads) after one warm-up pass", "host_cpus": os.cpu_count()}
+    return line
 
 
 # ----------------------------------------------------------------------------------------------- configs[3]: GNN
@@ -451,7 +519,7 @@ def base_line(metric, unit, value, world, args, elapsed, dtype):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", choices=("mil", "gnn"), default="mil")
+    ap.add_argument("--config", choices=("mil", "gnn", "vit"), default="mil")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
@@ -460,6 +528,7 @@ def main():
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--radiomics-dim", type=int, default=128)
     ap.add_argument("--graphs-per-step", type=int, default=256, help="gnn: graphs per optimizer step PER GPU")
+    ap.add_argument("--images-per-step", type=int, default=2048, help="vit: images per forward PER GPU")
     ap.add_argument("--nodes", type=int, default=196)
     ap.add_argument("--feat", type=int, default=768)
     ap.add_argument("--hidden", type=int, default=128)
@@ -492,7 +561,7 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    line = (run_mil if args.config == "mil" else run_gnn)(args, world, rank, dev)
+    line = {"mil": run_mil, "gnn": run_gnn, "vit": run_vit}[args.config](args, world, rank, dev)
     if rank == 0:
         line["kernel_source_hash"] = kernel_source_hash()
         if args.rehearse_on_one_gpu:
