@@ -82,6 +82,13 @@ __device__ __forceinline__ float halo_row16_sum(float v) {               // sum 
   return v;
 }
 
+#ifdef HALO_STAMPS   // tests/probes/probe_halo_stamps.hip: per-tile phase timestamps of MFMA wave 0 of the first 256 blocks
+__device__ unsigned long long g_halo_stamps[256 * 64 * 4];
+#define HALO_STAMP(tl, k) do { if (threadIdx.x == 0 && blockIdx.x < 256 && (tl) < 64) g_halo_stamps[(blockIdx.x * 64 + (tl)) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HALO_STAMP(tl, k) do { } while (0)
+#endif
+
 // LDS map (bytes): [0, 2*PB) two patch buffers (PB = prows*128) | 3 weight stages | 128 B zeros | 1 KB DMA scratch |
 // 256 floats of statistics (STATS 2: 8 waves x 128 floats)
 //
@@ -213,6 +220,7 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    HALO_STAMP(tl, 0);                                     // tile set-up done, K loop starts
 
     for (int cc = 0; cc < a.cchunks; ++cc, ++gc) {
       const int pbase = (gc & 1) * PB;
@@ -247,6 +255,7 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
       }
     }
 
+    HALO_STAMP(tl, 1);                                     // K loop issued
     // ---- register-only epilogue: lane (fg, fr) holds, for MFMA tiles (i, 2t) and (i, 2t+1), the eight consecutive
     //      output channels n0 + wn*64 + 32t + 8fg + {0..7} of pixel m0 + wm*64 + i*16 + fr: one 16-byte access each.
     //      Every addend load is issued before the first store (vmcnt counts loads and stores in order: a load behind
@@ -410,6 +419,7 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
         __hip_atomic_fetch_add(sp + t * 32, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
+    HALO_STAMP(tl, 2);                                     // epilogue issued
   }
   }   // MFMA waves
 
