@@ -262,10 +262,10 @@ size_t isic_wgrad_c64_workspace_bytes(int N, int H, int W);
 int isic_wgrad_c64_launch(const uint16_t* x, const uint16_t* dy, float* dw, int N, int H, int W, void* workspace,
                           hipStream_t stream);
 
-// ... and of the 128 -> 128 3x3 layers (conv_wgrad_c128.hip)
-size_t isic_wgrad_c128_workspace_bytes(int N, int H, int W);
-int isic_wgrad_c128_launch(const uint16_t* x, const uint16_t* dy, float* dw, int N, int H, int W, void* workspace,
-                           hipStream_t stream);
+// ... and of the 3x3 layers with Cin % 128 == 0, Cout % 32 == 0: 128, 256, 512 channels (conv_wgrad_c128.hip)
+size_t isic_wgrad_c128_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int isic_wgrad_c128_launch(const uint16_t* x, const uint16_t* dy, float* dw, int N, int H, int W, int Cin, int Cout,
+                           void* workspace, hipStream_t stream);
 
 namespace {
 // the all-taps kernels are always used for the shapes they cover (no environment switches, no global state)
@@ -283,8 +283,8 @@ size_t isic_conv2d_wgrad_workspace_bytes(int N, int Cin, int Hout, int Wout, int
     const size_t c64 = isic_wgrad_c64_workspace_bytes(N, Hout, Wout);
     if (c64 > need) need = c64;
   }
-  if (Cin == 128 && Cout == 128 && Kh == 3 && Kw == 3) {
-    const size_t c128 = isic_wgrad_c128_workspace_bytes(N, Hout, Wout);
+  if (Cin % 128 == 0 && Cout % 32 == 0 && Kh == 3 && Kw == 3) {   // (a stride-2 layer of these widths asks for more than it uses)
+    const size_t c128 = isic_wgrad_c128_workspace_bytes(N, Hout, Wout, Cin, Cout);
     if (c128 > need) need = c128;
   }
   return need;
@@ -309,12 +309,12 @@ int isic_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dw, int
       return rc != ISIC_OK ? rc : isic_launch_status();
     }
   }
-  if (Cin == 128 && Cout == 128 && Kh == 3 && Kw == 3 && stride == 1 && pad == 1 && Hin == Hout && Win == Wout &&
+  if (Cin % 128 == 0 && Cout % 32 == 0 && Kh == 3 && Kw == 3 && stride == 1 && pad == 1 && Hin == Hout && Win == Wout &&
       wgrad_c128_enabled()) {
-    const size_t need = isic_wgrad_c128_workspace_bytes(N, Hin, Win);
+    const size_t need = isic_wgrad_c128_workspace_bytes(N, Hin, Win, Cin, Cout);
     if (need != 0) {
       if (workspace_bytes < need) return ISIC_ERR_WORKSPACE;
-      const int rc = isic_wgrad_c128_launch(x, dy, dw, N, Hin, Win, workspace, as_stream(stream));
+      const int rc = isic_wgrad_c128_launch(x, dy, dw, N, Hin, Win, Cin, Cout, workspace, as_stream(stream));
       return rc != ISIC_OK ? rc : isic_launch_status();
     }
   }

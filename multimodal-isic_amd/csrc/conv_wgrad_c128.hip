@@ -11,6 +11,13 @@
 // 16-channel halves of the slice.  X is staged by each of the four slice blocks (L2 hits), dY only by its own:
 // 121 staged bytes per MFMA against 250 for the one-tap-per-block kernel of conv_wgrad.hip.
 // Per-block partials go to the workspace with plain stores and are summed in a fixed order: no atomics.
+//
+// Round 2: the same kernel serves every 3x3 / stride-1 layer with Cin % 128 == 0 and Cout % 32 == 0 (ResNet-18 layer3:
+// 256 channels @ 14x14, layer4: 512 @ 7x7).  A block owns one (128-input-channel slice, 32-output-channel slice) PAIR --
+// the gradient of a pair is exactly the 128 -> 128 problem on strided tensors -- and small images are PACKED into the
+// 4 x 32 pixel tile: two 14-wide or four 7-wide images side by side in slots of 16 / 8 columns, the >= 1 empty columns
+// between them staged as zeros (they are the images' padding).  Only the staging waves' address arithmetic knows; the
+// MFMA waves see the same LDS images as before.  87.5 % of a tile's pixels are real at 28, 14 and 7 pixels alike.
 #include <mutex>
 
 #include "common.h"
@@ -30,10 +37,14 @@ constexpr int NDMA128 = 16;                         // per staging wave (4 x 16 
 constexpr int SLICE_ELEMS = 32 * 9 * 128;           // one block's partial gradient
 
 struct WC128Args {
-  const unsigned short* x;
-  const unsigned short* dy;
-  float* partial;       // [4 slices][blocks_per_slice][32][9][128]
+  const unsigned short* x;      // [N][H][W][Cx]
+  const unsigned short* dy;     // [N][H][W][Cy]
+  float* partial;               // [pairs][blocks_per_slice][32][9][128], pair = ci_slice * (Cy / 32) + co_slice
   int N, H, W, tiles_y, tiles_x, total_tiles, tiles_per_block, blocks_per_slice;
+  int Cx, Cy;                   // channels of x / dy (pixel strides)
+  int co_slices;                // Cy / 32
+  int pack, slot_shift;         // images per tile row (1, 2, 4) and log2 of their slot width (5, 4, 3)
+  int Wv;                       // width of the virtual image a tile row walks: W (pack 1) or 32
 };
 
 __device__ __attribute__((aligned(256))) unsigned char g_wc128_zeros[2048];
@@ -49,7 +60,8 @@ __global__ __launch_bounds__(768) void wgrad_c128_kernel(WC128Args a) {
   typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int slice = blockIdx.x / a.blocks_per_slice, bs = blockIdx.x - slice * a.blocks_per_slice;
+  const int pair = blockIdx.x / a.blocks_per_slice, bs = blockIdx.x - pair * a.blocks_per_slice;
+  const int ci_slice = pair / a.co_slices, slice = pair - ci_slice * a.co_slices;      // slice: 32 output channels
   const int t_begin = bs * a.tiles_per_block;
   const int ntl = min(a.total_tiles - t_begin, a.tiles_per_block);       // >= 1 by construction of the grid
 
@@ -67,7 +79,7 @@ __global__ __launch_bounds__(768) void wgrad_c128_kernel(WC128Args a) {
     struct Tile { int n, y0, x0; };
     auto advance = [&](Tile& tl) {
       tl.x0 += T_W;
-      if (tl.x0 >= a.W) {
+      if (tl.x0 >= a.Wv) {
         tl.x0 = 0; tl.y0 += T_H;
         if (tl.y0 >= a.H) { tl.y0 = 0; tl.n += 1; }
       }
@@ -85,33 +97,64 @@ __global__ __launch_bounds__(768) void wgrad_c128_kernel(WC128Args a) {
     const unsigned xsrc1 = (unsigned)(((((xl_slot >> 1) ^ (xl_px | 4)) << 1) | (xl_slot & 1)) << 4);    // bit 2 set
     const unsigned ysrc = (unsigned)(((((yl_slot >> 1) ^ ((yl_px >> 3) & 1)) << 1) | (yl_slot & 1)) << 4);
     const unsigned long long zeros = (unsigned long long)g_wc128_zeros;
+    // virtual column vc of tile-row group tl.n -> (image, real column): slot k = vc >> slot_shift holds image
+    // tl.n * pack + k, its columns 0 .. W-1 at the start of the slot; everything else is padding (zeros).
+    // The staging waves sit on the critical path (62 DMAs per tile over four waves), so everything that does not depend
+    // on the tile is computed ONCE per DMA group: the lane's slot, its byte offset from the tile's base pixel (32 bit),
+    // its column inside the image; a tile then costs a wave-uniform 64-bit base, one 64-bit add and three compares.
+    const int slot_mask = (1 << a.slot_shift) - 1;
+    const int xpix = a.Cx * 2, ypix = a.Cy * 2;                      // bytes per pixel
+    const unsigned long long xbase = (unsigned long long)a.x + (unsigned long long)ci_slice * 256;
+    const unsigned long long ybase = (unsigned long long)a.dy + (unsigned long long)slice * 64;
+    int g_off[NDMA128], g_col[NDMA128], g_slot[NDMA128];
+    unsigned g_dst[NDMA128], g_src[NDMA128];
+#pragma unroll
+    for (int j = 0; j < NDMA128; ++j) {
+      const int d = p + 4 * j;                                       // wave-uniform
+      if (d < XGROUPS) {
+        const int pr = d / 9, g = d - 9 * pr;
+        const int vc = -1 + 4 * g + xl_px;                           // relative to the tile's first column
+        const int k = a.pack == 1 ? 0 : (vc >> a.slot_shift), rc = a.pack == 1 ? vc : (vc & slot_mask);     // vc = -1: k = -1
+        g_slot[j] = k; g_col[j] = rc;
+        g_off[j] = ((k * a.H + (pr - 1)) * a.W + rc) * xpix;
+        g_src[j] = ((pr + (g >> 1)) & 1) ? xsrc1 : xsrc0;            // key bit ((row + (col >> 3)) & 1), col = 4g + ..
+        g_dst[j] = (unsigned)((pr * XPITCH + 4 * g) * 256);
+      } else if (d < XGROUPS + YGROUPS) {
+        const int g2 = d - XGROUPS;
+        const int r = g2 >> 1, c = 16 * (g2 & 1) + yl_px;            // tile row / column of this lane's pixel
+        const int k = a.pack == 1 ? 0 : (c >> a.slot_shift), rc = a.pack == 1 ? c : (c & slot_mask);
+        g_slot[j] = k; g_col[j] = rc;
+        g_off[j] = ((k * a.H + r) * a.W + rc) * ypix;
+        g_src[j] = ysrc;
+        g_dst[j] = (unsigned)(XB + g2 * 1024);
+      } else {
+        g_slot[j] = 0; g_col[j] = 0; g_off[j] = 0; g_src[j] = 0; g_dst[j] = 0;
+      }
+    }
     auto issue_tile = [&](const Tile& tl, int stage, bool live) {
-      const long long org = ((long long)tl.n * a.H + tl.y0) * a.W + tl.x0;               // pixel index of the tile origin
       const unsigned sbase = lds0 + (unsigned)stage * STG;
+      const long long porg = ((long long)tl.n * a.pack * a.H + tl.y0) * a.W + tl.x0;     // first pixel of the tile (slot 0)
+      const unsigned long long xt = xbase + (unsigned long long)(porg * xpix), yt = ybase + (unsigned long long)(porg * ypix);
+      const int imgs_left = a.N - tl.n * a.pack;                     // slots k < imgs_left hold an image
 #pragma unroll
       for (int j = 0; j < NDMA128; ++j) {
-        const int d = p + 4 * j;                                                         // wave-uniform
+        const int d = p + 4 * j;                                     // wave-uniform
         unsigned long long src;
         unsigned dst;
         bool real = live;
         if (d < XGROUPS) {
-          const int pr = d / 9, g = d - 9 * pr;
-          const int yy = tl.y0 - 1 + pr, xx = tl.x0 - 1 + 4 * g + xl_px;
-          const bool ok = real && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-          const unsigned long long pix = (unsigned long long)a.x +
-              (unsigned long long)((org + (long long)(pr - 1) * a.W - 1 + 4 * g + xl_px) * 256);
-          const int kv = (pr + (g >> 1)) & 1;                                            // ((row + (col >> 3)) & 1), col = 4g + ..
-          src = (ok ? pix : zeros) + (kv ? xsrc1 : xsrc0);
-          dst = sbase + (unsigned)((pr * XPITCH + 4 * g) * 256);
+          const int pr = d / 9;
+          const bool row_ok = (unsigned)(tl.y0 - 1 + pr) < (unsigned)a.H;                // wave-uniform
+          const bool ok = real && row_ok && (unsigned)(tl.x0 + g_col[j]) < (unsigned)a.W && (unsigned)g_slot[j] < (unsigned)imgs_left &&
+                          g_slot[j] < a.pack;
+          src = (ok ? xt + (long long)g_off[j] : zeros) + g_src[j];
+          dst = sbase + g_dst[j];
         } else if (d < XGROUPS + YGROUPS) {
-          const int g2 = d - XGROUPS;
-          const int r = g2 >> 1, c = 16 * (g2 & 1) + yl_px;                              // tile row / column of this lane's pixel
-          const int yy = tl.y0 + r, xx = tl.x0 + c;
-          const bool ok = real && yy < a.H && xx < a.W;
-          const unsigned long long pix = (unsigned long long)a.dy +
-              (unsigned long long)((org + (long long)r * a.W + c) * 256 + slice * 64);
-          src = (ok ? pix : zeros) + ysrc;
-          dst = sbase + (unsigned)(XB + g2 * 1024);
+          const int r = (d - XGROUPS) >> 1;
+          const bool row_ok = tl.y0 + r < a.H;
+          const bool ok = real && row_ok && tl.x0 + g_col[j] < a.W && g_slot[j] < imgs_left;
+          src = (ok ? yt + (long long)g_off[j] : zeros) + g_src[j];
+          dst = sbase + g_dst[j];
         } else {
           real = false;
           src = zeros + (unsigned)(lane * 16);
@@ -211,16 +254,16 @@ __global__ __launch_bounds__(768) void wgrad_c128_kernel(WC128Args a) {
       *reinterpret_cast<f32x4*>(part + ((size_t)(c2 * 16 + fi) * 9 + t) * 128 + wave * 16 + fg * 4) = acc[t][c2];
 }
 
-// dw[32 slice + co][tap][ci] += sum over the slice's blocks (fixed order): thread (q, grp) sums blocks grp, grp+16, ...
-// of four consecutive elements, the 16 group sums are combined through LDS in group order
+// dw[32 co_slice + co][tap][128 ci_slice + ci] += sum over the pair's blocks (fixed order): thread (q, grp) sums blocks
+// grp, grp+16, ... of four consecutive elements, the 16 group sums are combined through LDS in group order
 __global__ __launch_bounds__(256) void wgrad_c128_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                                 int blocks_per_slice) {
+                                                                 int blocks_per_slice, int co_slices, int Cin) {
   __shared__ f32x4 red[16][16];
   const int q = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  const size_t e4 = (size_t)blockIdx.x * 16 + q;                   // float4 index into the whole gradient
-  const int slice = (int)(e4 / (SLICE_ELEMS / 4));
-  const size_t l4 = e4 - (size_t)slice * (SLICE_ELEMS / 4);        // ... inside the slice
-  const float* base = partial + (size_t)slice * blocks_per_slice * SLICE_ELEMS;
+  const size_t e4 = (size_t)blockIdx.x * 16 + q;                   // float4 index into [pairs][32][9][128]
+  const int pair = (int)(e4 / (SLICE_ELEMS / 4));
+  const size_t l4 = e4 - (size_t)pair * (SLICE_ELEMS / 4);         // ... inside the pair: (co * 9 + tap) * 32 + ci / 4
+  const float* base = partial + (size_t)pair * blocks_per_slice * SLICE_ELEMS;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f};
   for (int b = grp; b < blocks_per_slice; b += 16) s0 += reinterpret_cast<const f32x4*>(base + (size_t)b * SLICE_ELEMS)[l4];
   red[grp][q] = s0;
@@ -229,12 +272,16 @@ __global__ __launch_bounds__(256) void wgrad_c128_reduce_kernel(const float* __r
     f32x4 t = red[0][q];
 #pragma unroll
     for (int g = 1; g < 16; ++g) t += red[g][q];
-    f32x4* out = reinterpret_cast<f32x4*>(dw) + e4;
+    const int ci_slice = pair / co_slices, co_slice = pair - ci_slice * co_slices;
+    const int row = (int)(l4 >> 5), ci4 = (int)(l4 & 31);           // row = co * 9 + tap
+    f32x4* out = reinterpret_cast<f32x4*>(dw + ((size_t)co_slice * 32 * 9 + row) * Cin + ci_slice * 128) + ci4;
     *out = *out + t;
   }
 }
 
-int wc128_plan(int N, int H, int W, int* tiles_per_block) {
+struct WC128Plan { int pack, slot_shift, Wv, tiles_y, tiles_x, total_tiles, tiles_per_block, blocks_per_pair, pairs; };
+
+bool wc128_plan(int N, int H, int W, int Cin, int Cout, WC128Plan& p) {
   static int cus = 0;
   if (cus == 0) {
     int dev = 0;
@@ -242,30 +289,42 @@ int wc128_plan(int N, int H, int W, int* tiles_per_block) {
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
       cus = 256;
   }
-  const int per_slice = cus >= 4 ? cus / 4 : 1;
-  const int64_t total = (int64_t)N * ceil_div(H, T_H) * ceil_div(W, T_W);
-  const int tpb = (int)ceil_div64(total, per_slice);
-  if (tiles_per_block) *tiles_per_block = tpb;
-  return (int)ceil_div64(total, tpb);                              // blocks per slice
+  if (Cin % 128 != 0 || Cout % 32 != 0 || N <= 0 || H <= 0 || W <= 0) return false;
+  p.pack = W <= 7 ? 4 : (W <= 15 ? 2 : 1);                        // >= 1 empty column between packed images
+  p.slot_shift = p.pack == 4 ? 3 : (p.pack == 2 ? 4 : 5);
+  p.Wv = p.pack == 1 ? W : T_W;
+  p.tiles_y = ceil_div(H, T_H);
+  p.tiles_x = ceil_div(p.Wv, T_W);
+  const int64_t total = (int64_t)ceil_div(N, p.pack) * p.tiles_y * p.tiles_x;
+  if (total > 0x7FFFFFFFLL || (int64_t)N * H * W * (Cin > Cout ? Cin : Cout) > 0x7FFFFFFFFFLL) return false;
+  p.total_tiles = (int)total;
+  p.pairs = (Cin / 128) * (Cout / 32);
+  const int per_pair = cus >= p.pairs ? cus / p.pairs : 1;
+  p.tiles_per_block = (int)ceil_div64(total, per_pair);
+  p.blocks_per_pair = (int)ceil_div64(total, p.tiles_per_block);
+  return true;
 }
 
 }  // namespace
 
-// bytes of workspace the 128 -> 128 kernel needs for N images of H x W (0: shape not handled)
-size_t isic_wgrad_c128_workspace_bytes(int N, int H, int W) {
-  if ((int64_t)N * ceil_div(H, T_H) * ceil_div(W, T_W) > 0x7FFFFFFFLL) return 0;
-  return (size_t)4 * wc128_plan(N, H, W, nullptr) * SLICE_ELEMS * sizeof(float);
+// bytes of workspace the all-taps kernel needs for N images of H x W with Cin -> Cout channels (0: shape not handled)
+size_t isic_wgrad_c128_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+  WC128Plan p;
+  if (!wc128_plan(N, H, W, Cin, Cout, p)) return 0;
+  return (size_t)p.pairs * p.blocks_per_pair * SLICE_ELEMS * sizeof(float);
 }
 
-// called by isic_conv2d_wgrad_bf16 for Cin = Cout = 128, 3x3, stride 1, pad 1
-int isic_wgrad_c128_launch(const uint16_t* x, const uint16_t* dy, float* dw, int N, int H, int W, void* workspace,
-                           hipStream_t stream) {
+// called by isic_conv2d_wgrad_bf16 for 3x3, stride 1, pad 1, Cin % 128 == 0, Cout % 32 == 0
+int isic_wgrad_c128_launch(const uint16_t* x, const uint16_t* dy, float* dw, int N, int H, int W, int Cin, int Cout,
+                           void* workspace, hipStream_t stream) {
+  WC128Plan p;
+  if (!wc128_plan(N, H, W, Cin, Cout, p)) return ISIC_ERR_UNSUPPORTED;
   WC128Args a;
   a.x = x; a.dy = dy; a.partial = reinterpret_cast<float*>(workspace);
   a.N = N; a.H = H; a.W = W;
-  a.tiles_y = ceil_div(H, T_H); a.tiles_x = ceil_div(W, T_W);
-  a.total_tiles = N * a.tiles_y * a.tiles_x;
-  a.blocks_per_slice = wc128_plan(N, H, W, &a.tiles_per_block);
+  a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x; a.total_tiles = p.total_tiles;
+  a.tiles_per_block = p.tiles_per_block; a.blocks_per_slice = p.blocks_per_pair;
+  a.Cx = Cin; a.Cy = Cout; a.co_slices = Cout / 32; a.pack = p.pack; a.slot_shift = p.slot_shift; a.Wv = p.Wv;
   static std::once_flag once;                    // thread-safe one-time attribute setup
   static hipError_t attr_rc = hipSuccess;
   std::call_once(once, [] {
@@ -273,8 +332,8 @@ int isic_wgrad_c128_launch(const uint16_t* x, const uint16_t* dy, float* dw, int
                                   LDS_ALL);
   });
   if (attr_rc != hipSuccess) return ISIC_ERR_LAUNCH;
-  hipLaunchKernelGGL(wgrad_c128_kernel, dim3(4 * a.blocks_per_slice), dim3(768), LDS_ALL, stream, a);
-  hipLaunchKernelGGL(wgrad_c128_reduce_kernel, dim3(4 * SLICE_ELEMS / 64), dim3(256), 0, stream, a.partial, dw,
-                     a.blocks_per_slice);
+  hipLaunchKernelGGL(wgrad_c128_kernel, dim3(p.pairs * p.blocks_per_pair), dim3(768), LDS_ALL, stream, a);
+  hipLaunchKernelGGL(wgrad_c128_reduce_kernel, dim3(p.pairs * (SLICE_ELEMS / 64)), dim3(256), 0, stream, a.partial, dw,
+                     p.blocks_per_pair, a.co_slices, Cin);
   return ISIC_OK;
 }

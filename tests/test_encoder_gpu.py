@@ -368,6 +368,41 @@ def test_conv_wgrad_all_taps_kernels(shape, C):
     assert torch.equal(got, run()), "the all-taps weight gradient must be reproducible run to run"
 
 
+@pytest.mark.parametrize("case", [(37, 14, 14, 256, 256), (41, 7, 7, 512, 512), (5, 14, 14, 128, 256), (9, 7, 7, 256, 192),
+                                  (3, 13, 15, 256, 64), (6, 5, 7, 128, 64), (4, 28, 28, 256, 128), (3, 20, 44, 128, 192)])
+def test_conv_wgrad_all_taps_channel_slices_and_packed_images(case):
+    """The all-taps weight gradient beyond 128 -> 128 @ 28x28: every (128-input-channel, 32-output-channel) pair is its
+    own block range on strided tensors, and 14-wide / 7-wide images are packed two / four to a 32-column tile with their
+    padding as the gap (ResNet-18 layer3 / layer4; odd image counts, widths that leave 1 or 2 gap columns, widths above
+    32 that tile).  fp64 reference from nine shifted matrix products; deterministic (no atomics)."""
+    from isic_hip.lib import call
+    N, H, W, Ci, Co = case
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(N, H, W, Ci, generator=g).to(DEV).to(BF)
+    dy = torch.randn(N, H, W, Co, generator=g).to(DEV).to(BF)
+    ws = torch.empty(call("isic_conv2d_wgrad_workspace_bytes", N, Ci, H, W, Co, 3, 3), device=DEV, dtype=torch.uint8)
+
+    def run():
+        dw = torch.zeros(Co, 3, 3, Ci, device=DEV)                       # [co][kh][kw][ci]
+        call("isic_conv2d_wgrad_bf16", x, dy, dw, N, H, W, Ci, H, W, Co, 3, 3, 1, 1, ws, ws.numel())
+        torch.cuda.synchronize()
+        return dw
+
+    got = run()
+    xp = F.pad(x.double(), (0, 0, 1, 1, 1, 1))
+    dyd = dy.double().reshape(-1, Co)
+    ref = torch.empty(Co, 3, 3, Ci, device=DEV, dtype=torch.float64)
+    for kh in range(3):
+        for kw in range(3):
+            ref[:, kh, kw, :] = dyd.t() @ xp[:, kh:kh + H, kw:kw + W, :].reshape(-1, Ci)
+    assert_close(got.cpu(), ref.cpu(), rtol=2e-5, atol=1e-6 * float(ref.abs().max().cpu()) + 1e-6, what=f"wgrad all-taps {case}")
+    assert torch.equal(got, run()), "the all-taps weight gradient must be reproducible run to run"
+    # it accumulates into the caller's gradient
+    dw2 = torch.ones(Co, 3, 3, Ci, device=DEV)
+    call("isic_conv2d_wgrad_bf16", x, dy, dw2, N, H, W, Ci, H, W, Co, 3, 3, 1, 1, ws, ws.numel())
+    assert torch.equal(dw2 - 1.0, (got + 1.0) - 1.0)
+
+
 @pytest.mark.parametrize("shape", [(2, 12, 12), (3, 9, 13), (2, 112, 112)])
 def test_stem_fused_bn_relu_maxpool_and_pooled_bn_backward(shape):
     """The stem fusions are bit-identical to the kernels they replace: bn_apply(+ReLU) -> maxpool forward, and
