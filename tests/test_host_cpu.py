@@ -204,3 +204,32 @@ def test_derm_dataset_dict_contract(tmp_path):
     batch = next(iter(torch.utils.data.DataLoader(ds2, batch_size=3)))
     assert batch["image"].shape == (3, 3, 50, 50) and batch["radiomics"].shape == (3, 102)
     assert batch["artifacts"].shape == (3, 6) and batch["target"].tolist() == [5, 5, 5] and len(batch["image_path"]) == 3
+
+
+def test_vit_encoder_host_surface_and_oracle():
+    """ViT-S/16 (BASELINE.json configs[4]) without a GPU: timm parameter names and shapes, frozen parameters, no CPU
+    fallback; the fp32 oracle's fp16-emulating mode stays within fp16 noise of its fp32 mode."""
+    import torch
+    from isic_hip.lib import IsicHipError
+    from isic_hip.vit import ViTSmallEncoder
+    from oracle import vit as ov
+    enc = ViTSmallEncoder(img_size=32)
+    shapes = ov.vit_shapes(img=32)
+    sd = enc.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    assert all(tuple(sd[k].shape) == tuple(v) for k, v in shapes.items())
+    assert sum(v.numel() for v in ViTSmallEncoder().state_dict().values()) == 21_664_896      # timm vit_small_patch16_224 (22,050,664) minus head, cls token and its position
+    assert all(not p.requires_grad for p in enc.parameters())
+    with pytest.raises(IsicHipError):
+        enc.run_tokens(torch.zeros(1, 3, 32, 32))
+    with pytest.raises(IsicHipError):
+        enc.train()
+    with pytest.raises(ValueError):
+        enc.run_tokens(torch.zeros(1, 3, 48, 48))
+    p = ov.init_params(1, img=32)
+    enc.load_state_dict(p)
+    assert all(torch.equal(enc.state_dict()[k], p[k]) for k in p)
+    x = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(0))
+    a, b = ov.forward_tokens(p, x), ov.forward_tokens(p, x, emulate_fp16=True)
+    assert a.shape == (2, 4, 384) and float((a - b).abs().max()) < 2e-2 * float(a.abs().max())
+    assert enc.flops_per_image() > 0
