@@ -191,6 +191,7 @@ def run_mil(args, world, rank, dev):
     sync = ddp.GradSync(flat.grad, world_size=world)
     ddp.attach(model.encoder, flat, sync)
     model.encoder.fuse_bn_backward = bool(args.bn_fusion)
+    model.encoder.wgrad_stream = bool(args.wgrad_stream)
 
     # synthetic ISIC-shaped data, resident in HBM (bf16 images as the dataset loader would hand them over)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -535,6 +536,9 @@ def main():
     ap.add_argument("--gnn-layers", type=int, default=3)
     ap.add_argument("--knn-k", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--wgrad-stream", action="store_true",
+                    help="mil: weight gradients on a second HIP stream (A/B; off by default: concurrent kernels blur the "
+                         "per-kernel timings the roofline is computed from)")
     ap.add_argument("--bn-fusion", action="store_true",
                     help="mil: fold the BatchNorm-backward reductions of stages 2-4 into the data gradients (A/B; off by default)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
