@@ -45,8 +45,11 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const unsigned short* __r
   float acc[2][8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; }
+  // a block sums a CONTIGUOUS range of rows (DRAM pages walked in order: 5.8 -> 6.2 TB/s for the backward sums)
+  const int64_t per_block = ((rows + gridDim.x - 1) / gridDim.x + rls - 1) / rls * rls;
+  const int64_t r_end = min(rows, ((int64_t)blockIdx.x + 1) * per_block);
 #pragma unroll 4
-  for (int64_t r = (int64_t)blockIdx.x * rls + rl; r < rows; r += (int64_t)gridDim.x * rls) {
+  for (int64_t r = (int64_t)blockIdx.x * per_block + rl; r < r_end; r += rls) {
     float f[8];
     unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(x + r * C + cg * 8)), f);
 #pragma unroll
@@ -199,8 +202,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const unsigned short
     acc[0][j] = 0.f; acc[1][j] = 0.f; mu[j] = mean[cg * 8 + j]; rs[j] = rstd[cg * 8 + j];
     sc[j] = from_x ? scale[cg * 8 + j] : 0.f; sh[j] = from_x ? shift[cg * 8 + j] : 0.f;
   }
+  // a block sums a CONTIGUOUS range of rows (not a grid-strided set): DRAM pages are walked in order
+  const int64_t per_block = ((rows + gridDim.x - 1) / gridDim.x + rls - 1) / rls * rls;
+  const int64_t r_end = min(rows, ((int64_t)blockIdx.x + 1) * per_block);
 #pragma unroll 2
-  for (int64_t r = (int64_t)blockIdx.x * rls + rl; r < rows; r += (int64_t)gridDim.x * rls) {
+  for (int64_t r = (int64_t)blockIdx.x * per_block + rl; r < r_end; r += rls) {
     float g[8], xv[8], yv[8];
     unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dy + r * C + cg * 8)), g);
     unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(x + r * C + cg * 8)), xv);
