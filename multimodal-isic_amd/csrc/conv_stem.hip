@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(StemArgs a) {
     const int oy0 = (t2 / a.tiles_w) * TH, ox0 = (t2 % a.tiles_w) * TW;
     lds_barrier();    // previous tile's patch and C tile fully consumed / weights visible (no wait for its stores)
     commit_patch(Ps, pre, tid);
-    __syncthreads();
+    lds_barrier();                                       // (NOT __syncthreads(): that drains vmcnt, i.e. waits for the previous
+                                                         //  tile's output stores to complete their round trip to memory)
     fetch_patch(pre, a, tile + gridDim.x, tid);          // next tile's loads fly under this tile's MFMAs and stores
 
     f32x4 acc[2][4];
