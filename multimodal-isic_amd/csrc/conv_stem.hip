@@ -85,7 +85,14 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(StemArgs a) {
 
   u32x2 pre[PATCH_PER_THREAD];
   fetch_patch(pre, a, blockIdx.x, tid);
-  double st_s = 0.0, st_q = 0.0;          // fused BatchNorm statistics: thread = (channel tid & 63, pixel quarter tid >> 6)
+  // fused BatchNorm statistics of the ROUNDED outputs, in registers over all tiles of the block: lane (fg, fi) owns
+  // channels 16j + 4fg + r of pixel column fi -- 16 sums + 16 sums of squares (fp32; ~800 values each), reduced over the
+  // 16 lanes of a DPP row and the four waves once, at the end (the LDS read-back loop this replaces cost 0.3 ms per step)
+  float st_s[4][4], st_q[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { st_s[j][r] = 0.f; st_q[j][r] = 0.f; }
   for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
     const int n = tile / (a.tiles_h * a.tiles_w);
     const int t2 = tile - n * (a.tiles_h * a.tiles_w);
@@ -129,19 +136,17 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(StemArgs a) {
         v[0] = (unsigned)f32_to_bf16_bits(acc[i][j][0]) | ((unsigned)f32_to_bf16_bits(acc[i][j][1]) << 16);
         v[1] = (unsigned)f32_to_bf16_bits(acc[i][j][2]) | ((unsigned)f32_to_bf16_bits(acc[i][j][3]) << 16);
         *reinterpret_cast<u32x2*>(Cs + p * CPAD + j * 16 + fg * 4) = v;
+        if (a.stat_sum) {
+          const bool in = (oy0 + wave * 2 + i < a.Hout) && (ox0 + fi < a.Wout);
+          const float r0 = in ? __uint_as_float(v[0] << 16) : 0.f, r1 = in ? __uint_as_float(v[0] & 0xFFFF0000u) : 0.f;
+          const float r2 = in ? __uint_as_float(v[1] << 16) : 0.f, r3 = in ? __uint_as_float(v[1] & 0xFFFF0000u) : 0.f;
+          st_s[j][0] += r0; st_q[j][0] += r0 * r0;
+          st_s[j][1] += r1; st_q[j][1] += r1 * r1;
+          st_s[j][2] += r2; st_q[j][2] += r2 * r2;
+          st_s[j][3] += r3; st_q[j][3] += r3 * r3;
+        }
       }
     lds_barrier();
-    if (a.stat_sum) {                                    // fp32 over the 32 pixels of this tile, fp64 across tiles
-      const int c = tid & 63, q = tid >> 6;
-      float s = 0.f, sq = 0.f;
-#pragma unroll 8
-      for (int p = q * 32; p < q * 32 + 32; ++p) {
-        const float v = bf16_bits_to_f32(Cs[p * CPAD + c]);
-        const bool in = (oy0 + (p >> 4) < a.Hout) && (ox0 + (p & 15) < a.Wout);
-        s += in ? v : 0.f; sq += in ? v * v : 0.f;
-      }
-      st_s += (double)s; st_q += (double)sq;
-    }
     for (int idx = tid; idx < TH * TW * 8; idx += 256) {
       const int p = idx >> 3, ch = idx & 7;
       const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
@@ -151,9 +156,25 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(StemArgs a) {
     }
   }
   if (a.stat_sum) {
-    const size_t slot = (size_t)(blockIdx.x % a.stat_slots) * 64 + (tid & 63);
-    atomicAdd(a.stat_sum + slot, st_s);
-    atomicAdd(a.stat_sumsq + slot, st_q);
+    // DPP row sums over the 16 pixel columns, then the four waves meet in LDS (the weight image is dead by now)
+    __shared__ float stat_red[2][4][64];
+    lds_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float sv = st_s[j][r], qv = st_q[j][r];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { sv += __shfl_xor(sv, o, 16); qv += __shfl_xor(qv, o, 16); }
+        if (fi == 0) { stat_red[0][wave][j * 16 + fg * 4 + r] = sv; stat_red[1][wave][j * 16 + fg * 4 + r] = qv; }
+      }
+    lds_barrier();
+    if (tid < 128) {
+      const int c = tid & 63, w = tid >> 6;
+      const float t = (stat_red[w][0][c] + stat_red[w][1][c]) + (stat_red[w][2][c] + stat_red[w][3][c]);
+      const size_t slot = (size_t)(blockIdx.x % a.stat_slots) * 64 + c;
+      atomicAdd((w == 0 ? a.stat_sum : a.stat_sumsq) + slot, (double)t);
+    }
   }
 }
 
