@@ -287,7 +287,7 @@ int isic_colsum_f32(const float* X, int M, int N, int ldx, float* out, float bet
   ISIC_CHECK_ARG(M >= 0 && N >= 0 && ldx >= N);
   if (N == 0) return ISIC_OK;
   ISIC_CHECK_ARG(X && out);
-  if (M >= 8192 && N % 4 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+  if (M >= 1024 && N % 4 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
     const int nv = N / 4;
     const int vgb = nv >= 64 ? 64 : nv > 16 ? 32 : 16;
     const int colblocks4 = ceil_div(nv, vgb);
