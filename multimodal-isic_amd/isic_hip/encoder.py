@@ -279,7 +279,7 @@ class ResNet18Encoder(nn.Module):
         st = self._bn_affine(c, name, acc)
         N, H, W, C = c.shape
         y = _empty(c.shape, c)
-        if relu and self.training:
+        if relu and self.training and (residual is not None or self.fuse_bn_backward):
             # the backward passes need the ReLU mask of relu(bn(c) [+ residual]): kept as 1 bit per element (with a
             # residual it cannot be recomputed from c; without one it is what the fused data-gradient epilogue reads)
             mask = torch.empty((N * H * W * C) // 8, device=c.device, dtype=torch.uint8)
