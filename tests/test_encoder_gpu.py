@@ -313,26 +313,33 @@ def test_dgrad_with_fused_relu_mask_and_bn_backward_sums(case, with_addend):
 
 def test_encoder_backward_with_and_without_fused_bn_reductions():
     """The whole ResNet-18 backward with the BatchNorm reductions folded into the data gradients (stages 2-4) against
-    the same backward with every reduction run as its own pass: the parameter gradients agree to bf16 noise."""
+    the same backward with every reduction run as its own pass, ON THE SAME FORWARD TAPE (two forwards differ in the last
+    bits of their fp32-atomic statistics, and 17 bf16 layers amplify that to the per-cent level: the comparison would
+    measure the forward's noise).  The two backward paths then differ only in how sum dz / sum dz*xhat are rounded."""
     from isic_hip.encoder import ResNet18Encoder
     torch.manual_seed(3)
     enc = ResNet18Encoder().to(DEV).train()
     x = torch.randn(6, 3, 64, 64, generator=torch.Generator().manual_seed(4)).to(DEV)
     gfeat = torch.randn(6, 512, generator=torch.Generator().manual_seed(5)).to(DEV)
-    state = {k: v.clone() for k, v in enc.state_dict().items()}
+    enc.fuse_bn_backward = True                                  # the forward keeps the bn1 ReLU masks the fused path reads
+    feat, tape = enc.run_forward(x, save=True)
 
     def grads(fused):
-        enc.load_state_dict(state)
         for p in enc.parameters():
             p.grad = None
         enc.fuse_bn_backward = fused
-        feat, tape = enc.run_forward(x, save=True)
         enc.run_backward(tape, gfeat)
         torch.cuda.synchronize()
         return {k: p.grad.detach().float().clone() for k, p in enc.named_parameters()}
-    a, b = grads(True), grads(False)
-    worst = max(float((a[k] - b[k]).abs().max() / (b[k].abs().max() + 1e-12)) for k in a)
-    assert worst <= 2e-2, worst                                  # different rounding points of dz sums; bf16 chain below
+    a, b, a2 = grads(True), grads(False), grads(True)
+    for k in a:
+        assert bool(torch.isfinite(a[k]).all()) and bool(torch.isfinite(b[k]).all()), k
+    rel = {k: float((a[k] - b[k]).abs().max() / (b[k].abs().max() + 1e-12)) for k in a}
+    worst = max(rel, key=rel.get)
+    assert rel[worst] <= 2e-2, (worst, rel[worst])
+    # the fused path is reproducible on a given tape wherever the weight-gradient kernel is (no atomics in its sums)
+    for k in ("layer2.1.conv1.weight", "layer3.1.conv2.weight", "layer4.1.conv1.weight", "layer2.1.bn1.weight", "layer4.1.bn2.bias"):
+        assert torch.equal(a[k], a2[k]), k
 
 
 @pytest.mark.parametrize("C", [64, 128])
