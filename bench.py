@@ -5,6 +5,10 @@
     python bench.py --config vit --gpus 1 --steps 10 --warmup 2       # configs[4]: frozen ViT-S/16 fp16 patch encoder (forward)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                     # bare: starts its own N child processes
+
+The default (mil) line also carries short runs of configs[3] and configs[4] as "gnn" and "vit" sub-objects, each with
+its own roofline and cpu_baseline (--no-sublines to skip).
 
 Prints ONE JSON line on rank 0 (contract in the repo instructions): whole-job units/s (bags or graphs) with
 inputs resident in HBM when the timed region starts, plus
@@ -93,6 +97,15 @@ class KernelTimer:
     def _event(self):
         return self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
 
+    _installed = None          # the ONE timer wrapped around lib.call in this process (sub-benchmarks reuse it)
+
+    @classmethod
+    def get(cls):
+        if cls._installed is None:
+            cls._installed = cls()
+            cls._installed.install()
+        return cls._installed
+
     def install(self):
         from isic_hip import lib
         orig = lib.call
@@ -137,31 +150,42 @@ class KernelTimer:
         return out
 
 
-def kernel_source_hash():
-    """Identity of the kernels a profile was taken with: sha256 over csrc/*.hip and csrc/*.h."""
+def kernel_source_hash(prefixes=None):
+    """Identity of the kernels a profile was taken with: sha256 over csrc/*.hip and csrc/*.h (``prefixes``: only the
+    files whose name starts with one of them, plus every header)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "multimodal-isic_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
+        if f.endswith(".h") or (f.endswith(".hip") and (prefixes is None or f.startswith(tuple(prefixes)))):
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(key, **match):
-    """HBM bytes per launch of the roofline kernel from the rocprofv3 PMC passes of THIS command (counters need runs
-    of their own: tools/collect_traffic.sh), committed under profiles/.  The profile is stamped with the kernel
-    source hash and the workload; anything that does not match the code being run is refused (-> None)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+# Which kernel files decide the HBM traffic of each roofline entry: a PMC profile stays valid while THESE are unchanged
+# (tests/test_host_cpu.py fails when a committed profile no longer matches, so a kernel commit cannot silently null it).
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+TRAFFIC_SOURCES = {
+    "mil": ("conv_igemm", "conv_halo", "conv_pgemm", "conv_c64"),      # kernels behind isic_conv2d_igemm_bf16
+    "gnn": ("graph",),                                                  # isic_spmm_csr_f32
+    "vit": ("gemm_f16",),                                               # isic_gemm_f16
+}
+
+
+def pmc_traffic(section, **match):
+    """HBM bytes per launch of a roofline entry from the rocprofv3 PMC passes of THIS command (counters need runs of
+    their own: tools/collect_traffic.sh writes profiles/r03_pmc_traffic.json).  Each section is stamped with the hash
+    of the kernel sources behind that entry and with the workload; anything that does not match the code being run is
+    refused (-> None)."""
     try:
-        d = json.load(open(path))
+        d = json.load(open(TRAFFIC_PROFILE))[section]
     except Exception:
         return None
-    if d.get("kernel_source_hash") != kernel_source_hash():
+    if d.get("kernel_source_hash") != kernel_source_hash(TRAFFIC_SOURCES[section]):
         return None
-    if any(d.get(k) != v for k, v in match.items()):
+    if any(d.get("workload", {}).get(k) != v for k, v in match.items()):
         return None
-    return d.get(key)
+    return d.get("hbm_bytes_per_launch")
 
 
 def split_by_class(records, steps):
@@ -201,8 +225,7 @@ def run_mil(args, world, rank, dev):
                + 0.25 * labels[s].view(B, 1, 1, 1, 1).float()).to(torch.bfloat16) for s in range(n_sets)]
     radiom = [torch.randn(B, R, device=dev, generator=g) + 0.25 * labels[s].view(B, 1).float() for s in range(n_sets)]
 
-    timer = KernelTimer()
-    timer.install()
+    timer = KernelTimer.get()
 
     def step(i):
         s = i % n_sets
@@ -241,7 +264,7 @@ def run_mil(args, world, rank, dev):
                                    "conv_igemm kernels; 38 launches per step)",
         "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-        "traffic": pmc_traffic("conv_igemm_hbm_bytes_per_launch", bags_per_step=B, patches=K, image_size=S),
+        "traffic": pmc_traffic("mil", bags_per_step=B, patches=K, image_size=S),
         "launches": n_launch, "avg_launch_ms": conv_ms / max(n_launch, 1),
         "algorithmic_gflop_per_launch": conv_fl / max(n_launch, 1) / 1e9,
         "share_of_step_time": conv_ms * 1e-3 / elapsed, "measured": "HIP events inside the timed region",
@@ -292,8 +315,7 @@ def run_vit(args, world, rank, dev):
     enc = ViTSmallEncoder(img_size=S).to(dev)
     gen = torch.Generator(device=dev).manual_seed(99 + rank)
     x = torch.randn(n_img, 3, S, S, device=dev, generator=gen)
-    timer = KernelTimer()
-    timer.install()
+    timer = KernelTimer.get()
 
     def step(i):
         return enc.run_tokens(x).sum()
@@ -319,7 +341,8 @@ def run_vit(args, world, rank, dev):
         "bound": "mfma", "kernel": "C-ABI entry isic_gemm_f16 (every Linear of the encoder with its bias / GELU / residual "
                                    "epilogue: 49 launches per forward)",
         "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-        "traffic": None, "launches": len(gemm), "avg_launch_ms": ms / max(len(gemm), 1),
+        "traffic": pmc_traffic("vit", images_per_step=n_img, image_size=S),
+        "launches": len(gemm), "avg_launch_ms": ms / max(len(gemm), 1),
         "algorithmic_gflop_per_launch": fl / max(len(gemm), 1) / 1e9, "share_of_step_time": ms * 1e-3 / elapsed,
         "measured": "HIP events inside the timed region",
     }
@@ -376,8 +399,7 @@ def run_gnn(args, world, rank, dev):
     store = T.GraphStore(records, dev, True, mode=model.graph_mode)
     gidx = torch.Generator(device=dev).manual_seed(7 + rank)
 
-    timer = KernelTimer()
-    timer.install()
+    timer = KernelTimer.get()
 
     def step(i):
         idx = torch.randint(0, n_graphs, (Gs,), device=dev, generator=gidx)      # drawn on the device: no host -> device copy
@@ -415,7 +437,7 @@ def run_gnn(args, world, rank, dev):
         "bound": "hbm", "kernel": "C-ABI entry isic_spmm_csr_f32 (GCNConv aggregation: neighbour gather + segmented sum, "
                                   "forward and transposed backward)",
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "traffic": pmc_traffic("spmm_hbm_bytes_per_launch", graphs_per_step=Gs, nodes=N, hidden=F),
+        "traffic": pmc_traffic("gnn", graphs_per_step=Gs, nodes=N, hidden=F, knn_k=k),
         "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1),
         "algorithmic_bytes_per_launch": Gs * per_graph, "compulsory_bytes_per_layer_per_graph": per_graph,
         "share_of_step_time": ms * 1e-3 / elapsed, "measured": "HIP events inside the timed region",
@@ -546,14 +568,20 @@ def main():
                     help="multi-rank REHEARSAL for a box with one GPU: every rank uses cuda:0 and the collectives run "
                          "over gloo.  Exercises sharding, the bucketed gradient exchange fired by a real backward and the "
                          "buffer averaging; the printed rate is NOT a scaling measurement (ranks share one GPU)")
+    ap.add_argument("--no-sublines", action="store_true",
+                    help="mil: do not attach the short configs[3] (gnn) and configs[4] (vit) runs to the line")
+    ap.add_argument("--sub-steps", type=int, default=20, help="timed steps of each attached sub-benchmark")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one process per GPU "
+                         f"(torch.distributed.run --nproc-per-node {args.gpus}, or plain `python bench.py --gpus N`)")
     if args.rehearse_on_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -565,7 +593,24 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    line = {"mil": run_mil, "gnn": run_gnn, "vit": run_vit}[args.config](args, world, rank, dev)
+    runners = {"mil": run_mil, "gnn": run_gnn, "vit": run_vit}
+    line = runners[args.config](args, world, rank, dev)
+    if args.config == "mil" and not args.no_sublines:
+        # BASELINE.json configs[3] and configs[4] ride on the SAME line (the driver parses one line): short runs of the
+        # graph step and of the ViT encoder, each with its own roofline and cpu_baseline
+        sub_args = argparse.Namespace(**vars(args))
+        sub_args.steps, sub_args.warmup = args.sub_steps, 3
+        sub_args.cpu_budget_s = min(args.cpu_budget_s, 12.0)
+        for name in ("gnn", "vit"):
+            release_device_memory()
+            try:
+                sub = runners[name](sub_args, world, rank, dev)
+            except Exception as e:                      # a sub-benchmark must never cost the headline line
+                sub = {"error": f"{type(e).__name__}: {e}"}
+                if world > 1:
+                    raise
+            if rank == 0:
+                line[name] = sub
     if rank == 0:
         line["kernel_source_hash"] = kernel_source_hash()
         if args.rehearse_on_one_gpu:
@@ -574,6 +619,42 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def release_device_memory():
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+
+
+def self_launch(args):
+    """``python bench.py --gpus N`` started bare (no torchrun): this parent has not touched the GPU (importing torch
+    and parsing arguments does not), so it starts one CHILD process per GPU with the torchrun environment
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), relays rank 0's JSON line and returns the worst exit code.  Children
+    are new processes (subprocess), never an exec of this one."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if not args.rehearse_on_one_gpu:
+        have = torch.cuda.device_count()            # counts devices without initialising the runtime
+        if have < n:
+            print(f"bench.py: --gpus {n} but {have} GPU(s) visible", file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out or "")
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 if __name__ == "__main__":

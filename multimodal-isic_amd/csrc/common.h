@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/isic_hip.h"
 
 #define ISIC_WAVE 64
@@ -29,6 +31,37 @@ static inline int isic_launch_status() {
 }
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---------------------------------------------------------------- per-device one-time host state
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count belong to a DEVICE, not to the process: a process
+// that drives two GPUs must set the attribute on both.  State is therefore keyed by hipGetDevice() (the device the
+// caller's stream belongs to: torch makes it current before it hands out a stream).
+constexpr int ISIC_MAX_DEVICES = 16;
+static inline int isic_current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+  return d;
+}
+struct IsicPerDeviceOnce {
+  std::once_flag flag[ISIC_MAX_DEVICES];
+  hipError_t rc[ISIC_MAX_DEVICES];
+};
+template <class Fn>
+static inline hipError_t isic_once_per_device(IsicPerDeviceOnce& o, Fn fn) {
+  const int d = isic_current_device() % ISIC_MAX_DEVICES;
+  std::call_once(o.flag[d], [&] { o.rc[d] = fn(); });
+  return o.rc[d];
+}
+static inline int isic_cu_count() {
+  static int cus[ISIC_MAX_DEVICES];                        // 0 = not asked yet; the race is benign (same value)
+  const int dev = isic_current_device();
+  int n = cus[dev % ISIC_MAX_DEVICES];
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev % ISIC_MAX_DEVICES] = n;
+  }
+  return n;
+}
 
 __host__ __device__ static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 __host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -12,7 +12,6 @@
 //
 // Same operand conventions as conv_igemm.hip (NHWC bf16 activations, [64][3][3][64] bf16 weights,
 // XOR-swizzled 128-byte LDS rows written lane-linearly by the DMA, D[co][pixel] accumulators).
-#include <mutex>
 
 #include "common.h"
 
@@ -237,8 +236,8 @@ constexpr int P_GROUPS = PH * PP / 8;             // 50 DMA groups of 8 pixels
 constexpr int P_BUF = P_GROUPS * 1024;            // 51,200 B per patch
 constexpr int P_NBUF = 3;
 constexpr int P_SCRATCH = P_NBUF * P_BUF;         // landing zone of the padding DMAs
-constexpr int P_STATS = P_SCRATCH + 1024;         // 2 x 64 floats: per-block BatchNorm partial sums
-constexpr int P_LDS = P_STATS + 512;              // 155,136 B: one block per CU
+constexpr int P_STATS = P_SCRATCH + 1024;         // 4 pixel-group waves x 2 x 64 floats: per-wave BatchNorm partial sums
+constexpr int P_LDS = P_STATS + 2048;             // 156,672 B: one block per CU
 constexpr int P_DMA = 7;                          // DMA instructions per wave and tile (8 waves x 7 >= 50)
 
 struct C64PArgs {
@@ -303,7 +302,6 @@ __global__ __launch_bounds__(512) void conv3x3_c64p_kernel(C64PArgs a) {
   const int ntl = min(a.total_tiles - t_begin, a.tiles_per_block);       // >= 1 by construction of the grid
   const int tiles_img = a.tiles_y * a.tiles_x;
   lds_float* stats_lds = (lds_float*)(smem + P_STATS);
-  if (STATS && tid < 128) stats_lds[tid] = 0.f;
 
   // wave-uniform tile coordinates, advanced incrementally (no divisions in the tile loop)
   struct Tile { int n, y0, x0, pix; };                                   // pix: pixel index of the tile origin
@@ -511,28 +509,32 @@ __global__ __launch_bounds__(512) void conv3x3_c64p_kernel(C64PArgs a) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const float s = row16_sum(s8[c]), q = row16_sum(q8[c]);
+      // DETERMINISTIC (round 3): every (pixel-group wave, channel) value has ONE writer and its own LDS word; the four
+      // pixel-group waves are added below in a fixed order (LDS atomics added them in arrival order: run-to-run noise
+      // in the last fp32 bits of the statistics, which 17 bf16 layers amplify to per cent in the gradients)
       if (fr == 0) {
-        __hip_atomic_fetch_add(stats_lds + co0 + c, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(stats_lds + 64 + co0 + c, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        stats_lds[pg * 128 + co0 + c] = s;
+        stats_lds[pg * 128 + 64 + co0 + c] = q;
       }
     }
     lds_barrier();
     if (tid < 128) {
       const size_t slot = (size_t)(blockIdx.x % a.stat_slots) * 64 + (tid & 63);
-      atomicAdd((tid < 64 ? a.stat_sum : a.stat_sumsq) + slot, (double)stats_lds[tid]);
+      const float v = (stats_lds[tid] + stats_lds[128 + tid]) + (stats_lds[256 + tid] + stats_lds[384 + tid]);
+      // (with stat_slots >= gridDim.x the slot row is this block's own: 0 + v is exact, bit-reproducible)
+      atomicAdd((tid < 64 ? a.stat_sum : a.stat_sumsq) + slot, (double)v);
     }
   }
 }
 
 template <bool STATS, bool ADDEND>
 int launch_c64p(const C64PArgs& a, int grid, hipStream_t stream) {
-  static std::once_flag once;                    // thread-safe one-time attribute setup
-  static hipError_t attr_rc = hipSuccess;
-  std::call_once(once, [] {
-    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64p_kernel<STATS, ADDEND>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  static IsicPerDeviceOnce once;              // hipFuncSetAttribute is per device (one flag set per template instance)
+  if (isic_once_per_device(once, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64p_kernel<STATS, ADDEND>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   P_LDS);
-  });
-  if (attr_rc != hipSuccess) return ISIC_ERR_LAUNCH;
+      }) != hipSuccess)
+    return ISIC_ERR_LAUNCH;
   hipLaunchKernelGGL((conv3x3_c64p_kernel<STATS, ADDEND>), dim3(grid), dim3(512), P_LDS, stream, a);
   return ISIC_OK;
 }
@@ -548,13 +550,7 @@ int isic_conv3x3_c64_launch(int variant, const uint16_t* in, const uint16_t* w, 
   const int64_t blocks = (int64_t)N * tiles_y * tiles_x;
   if (blocks > 0x7FFFFFFFLL) return ISIC_ERR_UNSUPPORTED;
   if (variant == 2 && !(stat_sum && addend)) {
-    static int cus = 0;
-    if (cus == 0) {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess ||
-          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-        cus = 256;
-    }
+    const int cus = isic_cu_count();
     C64PArgs a;
     a.in = in; a.w = w; a.out = out; a.addend = addend;
     a.stat_sum = stat_sum; a.stat_sumsq = stat_sumsq; a.stat_slots = stat_slots > 0 ? stat_slots : 1;
@@ -571,13 +567,12 @@ int isic_conv3x3_c64_launch(int variant, const uint16_t* in, const uint16_t* w, 
   a.stat_sum = stat_sum; a.stat_sumsq = stat_sumsq; a.stat_slots = stat_slots > 0 ? stat_slots : 1;
   a.N = N; a.H = H; a.W = W;
   a.tiles_y = tiles_y; a.tiles_x = tiles_x;
-  static std::once_flag once;                    // thread-safe one-time attribute setup
-  static hipError_t attr_rc = hipSuccess;
-  std::call_once(once, [] {
-    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  static IsicPerDeviceOnce once;              // hipFuncSetAttribute is per device (one flag set per template instance)
+  if (isic_once_per_device(once, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   LDS_BYTES);
-  });
-  if (attr_rc != hipSuccess) return ISIC_ERR_LAUNCH;
+      }) != hipSuccess)
+    return ISIC_ERR_LAUNCH;
   hipLaunchKernelGGL(conv3x3_c64_kernel, dim3((unsigned)blocks), dim3(256), LDS_BYTES, stream, a);
   return ISIC_OK;
 }

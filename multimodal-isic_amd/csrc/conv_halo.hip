@@ -27,7 +27,6 @@
 //
 // The reference has no convolution kernel of its own (its encoder is an un-vendored ConvMAE run through torch,
 // save_latent.py:42-60); BASELINE.json configs[1] names ResNet-18 (SURVEY.md 8d layer table).
-#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -90,7 +89,7 @@ __device__ unsigned long long g_halo_stamps[256 * 64 * 4];
 #endif
 
 // LDS map (bytes): [0, 2*PB) two patch buffers (PB = prows*128) | 3 weight stages | 128 B zeros | 1 KB DMA scratch |
-// 256 floats of statistics (STATS 2: 8 waves x 128 floats)
+// statistics: 8 MFMA waves x 128 floats (each wave's own slots)
 //
 // STATS: 0 none; 1 forward -- BatchNorm sum / sum of squares of the rounded outputs; 2 DATA GRADIENT FEEDING A
 // BatchNorm(+ReLU) BACKWARD -- the output g (+ addend) is the gradient of a ReLU(BatchNorm(y)) activation: the epilogue
@@ -183,8 +182,7 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
   } else {
   // ===================================================================== MFMA waves
   if (tid < 8) reinterpret_cast<u32x4*>(smem + off_zero)[tid] = (u32x4){0u, 0u, 0u, 0u};   // 128 B of zeros
-  if (STATS == 1 && tid < 256) stats_lds[tid] = 0.f;
-  if (STATS == 2 && tid < 512) { stats_lds[tid] = 0.f; stats_lds[tid + 512] = 0.f; }   // 8 waves x 2 x 64
+  if (STATS != 0 && tid < 512) { stats_lds[tid] = 0.f; stats_lds[tid + 512] = 0.f; }   // 8 waves x 2 x 64
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // ordered before the first barrier of the K loop
 
   const int fr = lane & 15, fg = lane >> 4;
@@ -401,12 +399,11 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
     }
     if (STATS == 1) {
       // lanes of one fg group (a DPP row of 16) hold the same 8 channels for 16 different pixels: every lane ends with
-      // the row totals of the 16 values (8 sums, 8 sums of squares) of a channel group, and lane fr contributes value
-      // #fr -- ONE 64-lane LDS atomic per channel group instead of 16 four-lane ones; the four wm waves of a channel
-      // half meet in LDS (fp32 per block, fp64 across blocks)
-      unsigned sb = (unsigned)(wn * 64 + fg * 8 + (fr >> 3) * 128 + (fr & 7));
-      asm volatile("" : "+v"(sb));
-      lds_float* sp = stats_lds + sb;
+      // the row totals of the 16 values (8 sums, 8 sums of squares) of a channel group, and lane fr keeps value #fr.
+      // DETERMINISTIC (round 3): a wave adds its tiles' values to its OWN LDS slots in tile order -- no LDS atomics, whose
+      // arrival order between the four wm waves changed the fp32 sums from run to run; the block's flush adds the four
+      // waves of a channel half in a fixed order (the STATS 2 scheme), and every block owns its own fp64 slot row.
+      lds_float* sp = stats_lds + wave * 128 + lane;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         float mine = 0.f;
@@ -416,7 +413,7 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
           mine = fr == c ? sv : mine;
           mine = fr == 8 + c ? qv : mine;
         }
-        __hip_atomic_fetch_add(sp + t * 32, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        sp[t * 64] += mine;
       }
     }
     HALO_STAMP(tl, 2);                                     // epilogue issued
@@ -427,17 +424,14 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
     lds_barrier();                                       // all sixteen waves: every tile's partial sums are in LDS
     if (tid < 256) {
       const size_t slot = (size_t)(blockIdx.x % a.stat_slots) * a.Cout + n0 + (tid & 127);
-      float v;
-      if (STATS == 2) {
-        // channel c of the slice = wn*64 + t*32 + fg*8 + e lives in lane fg*16 + e (+ 8 for the second sum) of the
-        // slots of waves wm*2 + wn, wm = 0..3
-        const int c = tid & 127, l = ((c >> 3) & 3) * 16 + (c & 7) + (tid < 128 ? 0 : 8), t = (c >> 5) & 1, wn_ = c >> 6;
-        v = 0.f;
+      // channel c of the slice = wn*64 + t*32 + fg*8 + e lives in lane fg*16 + e (+ 8 for the second sum) of the
+      // slots of waves wm*2 + wn, wm = 0..3
+      const int c = tid & 127, l = ((c >> 3) & 3) * 16 + (c & 7) + (tid < 128 ? 0 : 8), t = (c >> 5) & 1, wn_ = c >> 6;
+      float v = 0.f;
 #pragma unroll
-        for (int wm_ = 0; wm_ < 4; ++wm_) v += stats_lds[(wm_ * 2 + wn_) * 128 + t * 64 + l];
-      } else {
-        v = stats_lds[tid];
-      }
+      for (int wm_ = 0; wm_ < 4; ++wm_) v += stats_lds[(wm_ * 2 + wn_) * 128 + t * 64 + l];
+      // (an atomic only because a caller MAY pass fewer slot rows than blocks; with stat_slots >= gridDim.x the row is
+      //  this block's own and 0 + v is exact: bit-reproducible)
       atomicAdd((tid < 128 ? a.stat_sum : a.stat_sumsq) + slot, (double)v);
     }
   }
@@ -445,13 +439,12 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
 
 template <int STATS, bool ADDEND>
 int launch_halo(const HaloArgs& a, int grid, int lds, hipStream_t stream) {
-  static std::once_flag once;
-  static hipError_t attr_rc = hipSuccess;
-  std::call_once(once, [] {
-    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<STATS, ADDEND>),
+  static IsicPerDeviceOnce once;              // hipFuncSetAttribute is per device (one flag set per template instance)
+  if (isic_once_per_device(once, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<STATS, ADDEND>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MAX_PROWS * 128 + NWST * WSTAGE + 2176 + 3072);
-  });
-  if (attr_rc != hipSuccess) return ISIC_ERR_LAUNCH;
+      }) != hipSuccess)
+    return ISIC_ERR_LAUNCH;
   hipLaunchKernelGGL((conv_halo_kernel<STATS, ADDEND>), dim3(grid), dim3(1024), lds, stream, a);
   return ISIC_OK;
 }
@@ -469,14 +462,7 @@ int isic_conv_halo_launch(const uint16_t* in, const uint16_t* w, uint16_t* out, 
                           const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots,
                           const uint8_t* relu_mask, const uint16_t* yraw, hipStream_t stream) {
   if (!isic_conv_halo_supported(N, H, W, Cin, Cout)) return ISIC_ERR_UNSUPPORTED;
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    cus = n;
-  }
+  const int cus = isic_cu_count();
   HaloArgs a;
   a.in = in; a.w = w; a.out = out; a.addend = addend;
   a.stat_sum = stat_sum; a.stat_sumsq = stat_sumsq; a.stat_slots = stat_slots > 0 ? stat_slots : 1;

@@ -34,7 +34,6 @@
 // 3-stage variants are kept behind ISIC_CONV_MODE for A/B timing; measured slower.)
 #include <stdlib.h>
 
-#include <mutex>
 
 #include "common.h"
 #include "conv_args.h"
@@ -374,13 +373,12 @@ int launch_conv(const ConvArgsN& a, hipStream_t s) {
   constexpr int MAIN = ((MODE == 3 || MODE == 5) ? 3 : (MODE == 0 ? 1 : 2)) * STAGE;
   constexpr int THREADS = (MODE >= 4 ? 2 : 1) * MT;
   constexpr int LDS = MAIN > CBYTES ? MAIN : CBYTES;
-  static std::once_flag once;                    // one per template instance; thread-safe
-  static hipError_t attr_rc = hipSuccess;
-  std::call_once(once, [] {
-    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, MODE>),
+  static IsicPerDeviceOnce once;              // hipFuncSetAttribute is per device (one flag set per template instance)
+  if (isic_once_per_device(once, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-  });
-  if (attr_rc != hipSuccess) return ISIC_ERR_LAUNCH;
+      }) != hipSuccess)
+    return ISIC_ERR_LAUNCH;
   int maxM = 0;
   for (int i = 0; i < a.n; ++i) maxM = a.c[i].M > maxM ? a.c[i].M : maxM;
   dim3 grid(ceil_div(maxM, BM), a.c[0].Cout / BN, a.n);

@@ -21,7 +21,6 @@
 //
 // The reference has no convolution kernel of its own (its encoder is an un-vendored ConvMAE run through torch,
 // save_latent.py:42-60); BASELINE.json configs[1] names ResNet-18 (SURVEY.md 8d layer table).
-#include <mutex>
 
 #include "common.h"
 #include "conv_args.h"
@@ -34,7 +33,7 @@ constexpr int PM = 256;                     // block tile: PM pixels x PN output
 constexpr int P_A = PM * 128;               // bytes of A per K-tile
 constexpr int P_NST = 3;
 constexpr int p_stage(int PN) { return P_A + PN * 128; }
-constexpr int p_lds(int PN) { return P_NST * p_stage(PN) + 1024 + 1024; }   // ring | DMA scratch | 2 PN floats of statistics
+constexpr int p_lds(int PN) { return P_NST * p_stage(PN) + 1024 + 4096; }   // ring | DMA scratch | statistics: 8 MFMA waves x 128 floats
 
 struct PGemmArgs {
   ConvArgsN cls;
@@ -177,7 +176,7 @@ __global__ __launch_bounds__(1024) void conv_pgemm_kernel(PGemmArgs pa) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA may outlive the block's LDS allocation
   } else {
     // ===================================================================== MFMA waves
-    if (STATS && tid < 2 * PN) stats_lds[tid] = 0.f;
+    if (STATS && tid < 512) { stats_lds[tid] = 0.f; stats_lds[tid + 512] = 0.f; }      // 8 waves x 128 floats
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     const int fr = lane & 15, fg = lane >> 4;
@@ -240,9 +239,9 @@ __global__ __launch_bounds__(1024) void conv_pgemm_kernel(PGemmArgs pa) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) ad[i][t] = *reinterpret_cast<const u32x4*>(a.addend + off[i] + t * 32);
       }
-      unsigned sb = (unsigned)(wn * WN + fg * 8 + (fr >> 3) * PN + (fr & 7));
-      asm volatile("" : "+v"(sb));                         // the lane's statistics slot (value #fr of its channel group)
-      lds_float* sp = stats_lds + sb;
+      // DETERMINISTIC statistics (round 3): a wave adds to its OWN LDS slots in tile order (no LDS atomics in arrival
+      // order); the flush adds the four wm waves of a channel column in a fixed order, one fp64 slot row per block
+      lds_float* sp = stats_lds + wave * 128 + lane;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         float s8[8], q8[8];
@@ -277,7 +276,7 @@ __global__ __launch_bounds__(1024) void conv_pgemm_kernel(PGemmArgs pa) {
         }
         if (STATS) {
           // every lane of a DPP row (16 pixels) ends with the row totals of the 16 values (8 sums, 8 sums of squares);
-          // lane fr then contributes value #fr: ONE 64-lane LDS atomic per channel group instead of 16 four-lane ones
+          // lane fr keeps value #fr (fr < 8: sum of channel fg*8 + fr; else sum of squares of channel fg*8 + fr - 8)
           float mine = 0.f;
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
@@ -285,7 +284,7 @@ __global__ __launch_bounds__(1024) void conv_pgemm_kernel(PGemmArgs pa) {
             mine = fr == c ? sv : mine;
             mine = fr == 8 + c ? qv : mine;
           }
-          __hip_atomic_fetch_add(sp + t * 32, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          sp[t * 64] += mine;
         }
       }
     }
@@ -295,20 +294,26 @@ __global__ __launch_bounds__(1024) void conv_pgemm_kernel(PGemmArgs pa) {
     lds_barrier();                                         // all sixteen waves: every tile's partial sums are in LDS
     if (tid < 2 * PN) {
       const size_t slot = (size_t)((blockIdx.x + blockIdx.y) % a.stat_slots) * a.Cout + n0 + (tid & (PN - 1));
-      atomicAdd((tid < PN ? a.stat_sum : a.stat_sumsq) + slot, (double)stats_lds[tid]);
+      // channel c of the slice = wn*WN + t*32 + fg*8 + e lives in lane fg*16 + e (+ 8 for the sum of squares) of the
+      // slots of waves wm*2 + wn, wm = 0..3
+      const int c = tid & (PN - 1), wn_ = c / WN, t = (c % WN) >> 5, l = ((c >> 3) & 3) * 16 + (c & 7) + (tid < PN ? 0 : 8);
+      float v = 0.f;
+#pragma unroll
+      for (int wm_ = 0; wm_ < 4; ++wm_) v += stats_lds[(wm_ * 2 + wn_) * 128 + t * 64 + l];
+      // (with stat_slots >= gridDim.x the slot row is this block's own: 0 + v is exact, bit-reproducible)
+      atomicAdd((tid < PN ? a.stat_sum : a.stat_sumsq) + slot, (double)v);
     }
   }
 }
 
 template <int PN, bool STATS, bool ADDEND>
 int launch_pgemm(const PGemmArgs& pa, dim3 grid, hipStream_t stream) {
-  static std::once_flag once;
-  static hipError_t attr_rc = hipSuccess;
-  std::call_once(once, [] {
-    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pgemm_kernel<PN, STATS, ADDEND>),
+  static IsicPerDeviceOnce once;              // hipFuncSetAttribute is per device (one flag set per template instance)
+  if (isic_once_per_device(once, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pgemm_kernel<PN, STATS, ADDEND>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, p_lds(PN));
-  });
-  if (attr_rc != hipSuccess) return ISIC_ERR_LAUNCH;
+      }) != hipSuccess)
+    return ISIC_ERR_LAUNCH;
   hipLaunchKernelGGL((conv_pgemm_kernel<PN, STATS, ADDEND>), grid, dim3(1024), p_lds(PN), stream, pa);
   return ISIC_OK;
 }
@@ -318,14 +323,7 @@ int launch_pgemm(const PGemmArgs& pa, dim3 grid, hipStream_t stream) {
 // Called by isic_conv2d_igemm_bf16 (conv_igemm.hip) with the parity classes it has set up; Cout % 64 == 0
 // (128-channel slices when Cout % 128 == 0, else 64-channel slices).
 int isic_conv_pgemm_launch(const isic_conv::ConvArgsN& classes, hipStream_t stream) {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    cus = n;
-  }
+  const int cus = isic_cu_count();
   const ConvArgs& a0 = classes.c[0];
   if (a0.Cout % 64 != 0 || classes.n < 1) return ISIC_ERR_UNSUPPORTED;
   const int PN = a0.Cout % 128 == 0 ? 128 : 64;

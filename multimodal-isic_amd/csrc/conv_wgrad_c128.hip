@@ -18,7 +18,6 @@
 // 4 x 32 pixel tile: two 14-wide or four 7-wide images side by side in slots of 16 / 8 columns, the >= 1 empty columns
 // between them staged as zeros (they are the images' padding).  Only the staging waves' address arithmetic knows; the
 // MFMA waves see the same LDS images as before.  87.5 % of a tile's pixels are real at 28, 14 and 7 pixels alike.
-#include <mutex>
 
 #include "common.h"
 
@@ -282,13 +281,7 @@ __global__ __launch_bounds__(256) void wgrad_c128_reduce_kernel(const float* __r
 struct WC128Plan { int pack, slot_shift, Wv, tiles_y, tiles_x, total_tiles, tiles_per_block, blocks_per_pair, pairs; };
 
 bool wc128_plan(int N, int H, int W, int Cin, int Cout, WC128Plan& p) {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
-  }
+  const int cus = isic_cu_count();
   if (Cin % 128 != 0 || Cout % 32 != 0 || N <= 0 || H <= 0 || W <= 0) return false;
   p.pack = W <= 7 ? 4 : (W <= 15 ? 2 : 1);                        // >= 1 empty column between packed images
   p.slot_shift = p.pack == 4 ? 3 : (p.pack == 2 ? 4 : 5);
@@ -325,13 +318,12 @@ int isic_wgrad_c128_launch(const uint16_t* x, const uint16_t* dy, float* dw, int
   a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x; a.total_tiles = p.total_tiles;
   a.tiles_per_block = p.tiles_per_block; a.blocks_per_slice = p.blocks_per_pair;
   a.Cx = Cin; a.Cy = Cout; a.co_slices = Cout / 32; a.pack = p.pack; a.slot_shift = p.slot_shift; a.Wv = p.Wv;
-  static std::once_flag once;                    // thread-safe one-time attribute setup
-  static hipError_t attr_rc = hipSuccess;
-  std::call_once(once, [] {
-    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_c128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  static IsicPerDeviceOnce once;              // hipFuncSetAttribute is per device (one flag set per template instance)
+  if (isic_once_per_device(once, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_c128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   LDS_ALL);
-  });
-  if (attr_rc != hipSuccess) return ISIC_ERR_LAUNCH;
+      }) != hipSuccess)
+    return ISIC_ERR_LAUNCH;
   hipLaunchKernelGGL(wgrad_c128_kernel, dim3(p.pairs * p.blocks_per_pair), dim3(768), LDS_ALL, stream, a);
   hipLaunchKernelGGL(wgrad_c128_reduce_kernel, dim3(p.pairs * (SLICE_ELEMS / 64)), dim3(256), 0, stream, a.partial, dw,
                      p.blocks_per_pair, a.co_slices, Cin);

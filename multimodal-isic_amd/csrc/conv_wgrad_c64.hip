@@ -14,7 +14,6 @@
 // the K axis (pixels) is the row axis of the NHWC images in LDS.
 // The partial gradients of the blocks go to the workspace with plain stores and are summed by a second kernel in
 // a fixed order: the result does not depend on the scheduling (no atomics).
-#include <mutex>
 
 #include "common.h"
 
@@ -254,13 +253,7 @@ __global__ __launch_bounds__(256) void wgrad_c64_reduce_kernel(const float* __re
 }
 
 int wc64_blocks(int N, int H, int W, int* tiles_per_block) {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
-  }
+  const int cus = isic_cu_count();
   const int64_t total = (int64_t)N * ceil_div(H, WT_H) * ceil_div(W, WT_W);
   const int tpb = (int)ceil_div64(total, cus);
   if (tiles_per_block) *tiles_per_block = tpb;
@@ -284,13 +277,12 @@ int isic_wgrad_c64_launch(const uint16_t* x, const uint16_t* dy, float* dw, int 
   a.tiles_y = ceil_div(H, WT_H); a.tiles_x = ceil_div(W, WT_W);
   a.total_tiles = N * a.tiles_y * a.tiles_x;
   const int grid = wc64_blocks(N, H, W, &a.tiles_per_block);
-  static std::once_flag once;                    // thread-safe one-time attribute setup
-  static hipError_t attr_rc = hipSuccess;
-  std::call_once(once, [] {
-    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  static IsicPerDeviceOnce once;              // hipFuncSetAttribute is per device (one flag set per template instance)
+  if (isic_once_per_device(once, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   LDS_TOTAL);
-  });
-  if (attr_rc != hipSuccess) return ISIC_ERR_LAUNCH;
+      }) != hipSuccess)
+    return ISIC_ERR_LAUNCH;
   hipLaunchKernelGGL(wgrad_c64_kernel, dim3(grid), dim3(768), LDS_TOTAL, stream, a);
   hipLaunchKernelGGL(wgrad_c64_reduce_kernel, dim3(DW_ELEMS / 64), dim3(256), 0, stream, a.partial, dw, grid);
   return ISIC_OK;

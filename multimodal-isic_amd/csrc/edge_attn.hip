@@ -97,12 +97,16 @@ __global__ __launch_bounds__(256) void edge_attn_bwd_dst_kernel(const float* __r
                                                                  float scale, unsigned thr, float dscale,
                                                                  unsigned long long seed, unsigned long long stream_id) {
   __shared__ float sda[4][MAXE];
-  constexpr int MAXV = 8;                                          // H*F <= 64*MAXV values of d att per lane
+  // d att[h, f]: lane l owns the elements f = l + 64 q of every head, slot = h * QF + q with QF = ceil(F / 64).  Up to
+  // MAXV slots stay in registers over all rows of the wave (any F, any H with H * QF <= MAXV: 4 heads x 256, 4 x 32,
+  // 1 x 1024 ...); wider layers add their row's contribution with one atomic per element instead.
+  constexpr int MAXV = 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float datt_acc[MAXV];
 #pragma unroll
   for (int q = 0; q < MAXV; ++q) datt_acc[q] = 0.f;
-  const int HF = H * F;
+  const int QF = (F + 63) / 64;
+  const bool in_regs = H * QF <= MAXV;
   for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < N; i += (int64_t)gridDim.x * 4) {
     const int b = rowptr[i], e = rowptr[i + 1];
     const bool in_lds = (e - b) <= MAXE;
@@ -144,18 +148,23 @@ __global__ __launch_bounds__(256) void edge_attn_bwd_dst_kernel(const float* __r
         }
         dqd[(i * H + h) * F + f0] = acc;
         if (MODE == EA_GATV2) {
-          const int slot = (h * F + f0) / 64;                      // element h*F + f0 = lane + 64*slot when F % 64 == 0
-          if (slot < MAXV) datt_acc[slot] += da_acc;
+          if (in_regs) {
+            const int slot = h * QF + q;
+#pragma unroll
+            for (int t = 0; t < MAXV; ++t) datt_acc[t] += (t == slot) ? da_acc : 0.f;
+          } else {
+            atomicAdd(datt + h * F + f0, da_acc);
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();                             // sda is reused by the next head
     }
   }
-  if (MODE == EA_GATV2) {
+  if (MODE == EA_GATV2 && in_regs) {
 #pragma unroll
-    for (int q = 0; q < MAXV; ++q) {
-      const int idx = lane + 64 * q;
-      if (idx < HF) atomicAdd(datt + idx, datt_acc[q]);
+    for (int t = 0; t < MAXV; ++t) {
+      const int h = t / QF, f = lane + 64 * (t % QF);
+      if (h < H && f < F) atomicAdd(datt + h * F + f, datt_acc[t]);
     }
   }
 }
@@ -331,7 +340,6 @@ int isic_edge_attn_bwd(int mode, const float* dout, const float* ks, const float
   if (N == 0) return ISIC_OK;
   ISIC_CHECK_ARG(dout && ks && qd && v && alpha && rowptr && col && rowptr_t && col_t && perm_t && de && dqd && dks);
   ISIC_CHECK_ARG(mode == EA_GATV2 ? (att && datt) : (dv != nullptr));
-  if (mode == EA_GATV2 && ((F % 64) != 0 || (int64_t)H * F > 512)) return ISIC_ERR_UNSUPPORTED;   // d att register layout
   hipStream_t s = as_stream(stream);
   return mode == EA_GATV2 ? launch_bwd<EA_GATV2>(dout, ks, qd, v, att, alpha, rowptr, col, rowptr_t, col_t, perm_t, de, dqd,
                                                  dks, dv, datt, N, H, F, negative_slope, scale, drop_threshold, drop_scale,

@@ -14,7 +14,6 @@
 //
 // The reference's encoder is an un-vendored ConvMAE conv-ViT run frozen under no_grad (save_latent.py:42-60); this is
 // this build's definition of the ViT-S/16 named by BASELINE.json (oracle/vit.py restates it on the CPU in fp32).
-#include <mutex>
 
 #include "common.h"
 
@@ -215,13 +214,12 @@ __global__ __launch_bounds__(1024) void gemm_f16_kernel(GemmF16Args a) {
 
 template <int GELU, bool RES>
 int launch_g16(const GemmF16Args& a, dim3 grid, hipStream_t stream) {
-  static std::once_flag once;
-  static hipError_t attr_rc = hipSuccess;
-  std::call_once(once, [] {
-    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<GELU, RES>),
+  static IsicPerDeviceOnce once;              // hipFuncSetAttribute is per device (one flag set per template instance)
+  if (isic_once_per_device(once, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<GELU, RES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
-  });
-  if (attr_rc != hipSuccess) return ISIC_ERR_LAUNCH;
+      }) != hipSuccess)
+    return ISIC_ERR_LAUNCH;
   hipLaunchKernelGGL((gemm_f16_kernel<GELU, RES>), grid, dim3(1024), G_LDS, stream, a);
   return isic_launch_status();
 }
@@ -237,14 +235,7 @@ int isic_gemm_f16(const uint16_t* A, const uint16_t* W, const float* bias, const
   ISIC_CHECK_ARG(A && W && C);
   ISIC_CHECK_ARG(residual || residual_rows == 0);
   if (N % GN != 0 || K % 64 != 0) return ISIC_ERR_UNSUPPORTED;
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    cus = n;
-  }
+  const int cus = isic_cu_count();
   GemmF16Args a;
   a.A = A; a.W = W; a.bias = bias; a.res = residual; a.C = C;
   a.M = M; a.N = N; a.K = K; a.Ktiles = K / 64; a.act = act; a.res_rows = residual_rows;

@@ -5,7 +5,6 @@
 // ViT-S/16 named by BASELINE.json configs[4] with timm semantics (pre-norm blocks, LayerNorm eps 1e-6, scaled dot
 // product attention without a class token or masking: save_latent.py passes mask_ratio = 0).  oracle/vit.py is the fp32
 // CPU restatement.
-#include <mutex>
 
 #include "common.h"
 
@@ -277,13 +276,12 @@ int isic_attention_f16(const uint16_t* qkv, uint16_t* out, int n_images, int tok
                        void* stream) {
   ISIC_CHECK_ARG(qkv && out && n_images > 0 && tokens > 0 && heads > 0);
   if (head_dim != 64 || tokens > AT_TMAX) return ISIC_ERR_UNSUPPORTED;
-  static std::once_flag once;
-  static hipError_t attr_rc = hipSuccess;
-  std::call_once(once, [] {
-    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_f16_kernel),
+  static IsicPerDeviceOnce once;              // hipFuncSetAttribute is per device (one flag set per template instance)
+  if (isic_once_per_device(once, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(attention_f16_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS);
-  });
-  if (attr_rc != hipSuccess) return ISIC_ERR_LAUNCH;
+      }) != hipSuccess)
+    return ISIC_ERR_LAUNCH;
   const float scale_log2e = 0.125f * 1.4426950408889634f;            // 1 / sqrt(64), base-2 exponent
   hipLaunchKernelGGL(attention_f16_kernel, dim3(n_images * heads), dim3(AT_WAVES * 64), AT_LDS, as_stream(stream), qkv, out, tokens,
                      heads, scale_log2e);

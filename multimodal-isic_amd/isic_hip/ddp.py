@@ -22,9 +22,12 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, flat_grad, world_size=None, bucket_bytes=16 << 20, group=None):
+    def __init__(self, flat_grad, world_size=None, bucket_bytes=16 << 20, group=None, force_collectives=False):
+        """``force_collectives``: launch the all-reduces even at world size 1 (an identity there) -- the way to put
+        RCCL, its stream and the ordering against the backward / weight-gradient streams under test on ONE GPU."""
         self.buf = flat_grad
         self.group = group
+        self.force = bool(force_collectives)
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.bucket_elems = max(1, int(bucket_bytes) // flat_grad.element_size())
         self.reset()
@@ -38,7 +41,7 @@ class GradSync:
         if hi <= lo:
             return
         self.launched.append((lo, hi))
-        if self.world > 1:
+        if self.world > 1 or self.force:
             self.work.append(dist.all_reduce(self.buf[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def mark_ready(self, lo):

@@ -89,6 +89,7 @@ class ResNet18Encoder(nn.Module):
         # 2048 images: BatchNorm passes -1.0 ms, data gradients +0.75 ms per step -> +0.6 % bags/s, inside the run-to-run
         # noise, while the convolution entry's roofline fraction drops 0.369 -> 0.352: off by default, kept as an option.
         self.fuse_bn_backward = False
+        self._tape_fused = False      # fusion mode of the tape being replayed (recorded at forward time)
         self.grad_ready_hook = None   # callable(list_of_param_names) fired as gradients complete (DDP overlap)
 
     # parameters are registered under dotted torchvision names via nested holder modules
@@ -175,8 +176,10 @@ class ResNet18Encoder(nn.Module):
         return dx
 
     def _dgrad_bnbwd_ok(self, dy_shape, name, in_shape):
-        """Is there a fused kernel for `dgrad(dy) -> ReLU mask -> BatchNorm-backward sums` of this layer?"""
-        if not self.fuse_bn_backward:
+        """Is there a fused kernel for `dgrad(dy) -> ReLU mask -> BatchNorm-backward sums` of this layer?  Decided by
+        the mode the TAPE was recorded in (``_tape_fused``, set by ``run_backward`` from the tape), not by the live
+        attribute: toggling ``fuse_bn_backward`` between forward and backward must not change the path half-way."""
+        if not self._tape_fused:
             return False
         sp = self.specs[name]
         N, H, W, C = in_shape
@@ -440,7 +443,8 @@ class ResNet18Encoder(nn.Module):
         am = torch.empty((N, Hp, Wp, 64), device=c.device, dtype=torch.uint8) if save else None
         csel = _empty((N, Hp, Wp, 64), c) if save else None    # raw stem output at each window's argmax (bn1 backward sums)
         call("isic_bn_relu_maxpool3x3s2_fwd_sel_bf16", c, st0[2], st0[3], p, am, csel, N, Ho, Wo, 64, Hp, Wp)
-        tape = {"x0": x0, "stem": (c, st0, am, csel, (N, Ho, Wo, 64)), "blocks": []} if save else None
+        tape = {"x0": x0, "stem": (c, st0, am, csel, (N, Ho, Wo, 64)), "blocks": [],
+                "fused_bn_backward": bool(self.fuse_bn_backward)} if save else None
         x = p
         for pre, ds in self.blocks:
             x, saved = self.block_forward(x, pre, ds)
@@ -491,6 +495,7 @@ class ResNet18Encoder(nn.Module):
         if not self.training:
             raise IsicHipError("encoder backward needs train() mode (batch-statistics BatchNorm)")
         N, Hf, Wf, Cf = tape["final_shape"]
+        self._tape_fused = bool(tape.get("fused_bn_backward", False))
         self._arena_reset(dfeat.device)
         g = torch.empty((N, Hf, Wf, Cf), device=dfeat.device, dtype=_BF16)
         call("isic_avgpool_bwd_bf16", dfeat.float().contiguous(), g, N, Hf * Wf, Cf)

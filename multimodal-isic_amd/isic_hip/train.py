@@ -174,6 +174,103 @@ def collect_teacher_outputs(model, bags, labels, image_ids, device, chunk=64):
     return pd.DataFrame(rows)
 
 
+# ----------------------------------------------------------------------------- configs[1]: bags of image patches
+class ImageBagStore:
+    """Bags of K image patches + one radiomic vector per bag, resident in HBM (images as bf16: what the encoder's
+    first kernel rounds to anyway)."""
+
+    def __init__(self, images, radiomics, labels, device):
+        images = torch.as_tensor(images)
+        if images.dim() != 5:
+            raise ValueError(f"expected images[n, K, 3, H, W], got {tuple(images.shape)}")
+        self.images = images.to(device=device, dtype=torch.bfloat16)
+        self.radiomics = torch.as_tensor(radiomics, dtype=torch.float32).to(device)
+        self.labels = np.asarray(labels)
+        self.y_dev = torch.as_tensor(self.labels, device=device)
+        self.device = device
+
+    def __len__(self):
+        return len(self.labels)
+
+    def batch(self, idx):
+        sel = torch.as_tensor(list(idx), device=self.device)
+        return self.images[sel], self.radiomics[sel], self.y_dev[sel]
+
+
+@torch.no_grad()
+def eval_milnet(model, store, chunk=64):
+    """Fused-logit class probabilities and mean per-bag CE over all bags, eval mode (running BatchNorm statistics,
+    no dropout) -- the evaluation of `01_train_mil_teacher.py:247-260` for the composed model."""
+    model.eval()
+    probs, losses = [], []
+    for lo in range(0, len(store), chunk):
+        img, rad, y = store.batch(range(lo, min(len(store), lo + chunk)))
+        out = model(img, rad)
+        losses.append(ops.CrossEntropyFn.apply(out["logits"], y, 0)[1].cpu())
+        probs.append(ops.softmax_rows(out["logits"]).cpu())
+    if not probs:
+        return np.zeros((0, 0), np.float32), float("nan")
+    return torch.cat(probs).numpy(), float(torch.cat(losses).mean())
+
+
+def train_milnet_fold(model, train_set, val_set, *, optimizer="adamw", lr=2.2e-4, weight_decay=8.6e-4, epochs=200,
+                      patience=8, bags_per_step=8, seed=42, num_classes=7, device=None, log=print):
+    """The 01 loop (`01_train_mil_teacher.py:203-290`) for BASELINE.json configs[1]: ``model.MultiModalMILNet`` (ResNet-18
+    patch encoder -> attention-MIL head -> radiomic fusion) trained end to end on bags of image patches.  Class-balanced
+    sampler stream (`01:189-193`), ``bags_per_step`` bags per optimizer step and rank (bag-sharded DDP: every rank draws
+    the same stream and takes its slice; gradients all-reduced through ``ddp.GradSync`` overlapped with the encoder's
+    backward), validation after every epoch -> macro one-vs-rest AUROC / balanced accuracy / loss of the fused logits,
+    best states by balanced accuracy and by loss, early stop on the loss (`01:265-290`).
+    ``train_set`` / ``val_set`` = (images[n, K, 3, H, W], radiomics[n, R], labels[n])."""
+    from sklearn.metrics import balanced_accuracy_score
+    rank, world = dist_info()
+    device = device or next(model.parameters()).device
+    tr, va = ImageBagStore(*train_set, device), ImageBagStore(*val_set, device)
+    opt = _make_optimizer(model, optimizer, lr, weight_decay)
+    ddp.broadcast_parameters(opt.flat.data)
+    sync = ddp.GradSync(opt.flat.grad, world_size=world)
+    ddp.attach(model.encoder, opt.flat, sync)
+    gen = torch.Generator().manual_seed(seed)
+    best = {"bacc": -np.inf, "loss": float("inf"), "state_bacc": None, "state_loss": None, "no_improve": 0}
+    history = []
+    per_step = bags_per_step * world
+    snapshot = lambda: {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    for epoch in range(1, epochs + 1):
+        model.train()
+        order = weighted_sample_indices(tr.labels, gen)
+        for s in range(0, len(order), per_step):
+            glob = order[s:s + per_step]
+            lo, hi = ddp.shard_range(len(glob), rank, world)
+            mine = glob[lo:hi]
+            opt.zero_grad()
+            sync.reset()
+            if mine:
+                img, rad, y = tr.batch(mine)
+                out = model(img, rad)
+                (model.loss(out, y) * (len(mine) * world / len(glob))).backward()
+            _sync_step(opt, sync, world)
+        ddp.average_buffers(model)               # BatchNorm running statistics are per rank during the epoch
+        probs, val_loss = eval_milnet(model, va)
+        if len(va) == 0:
+            break
+        m = gnn_metrics(va.labels, probs, num_classes)
+        bacc = balanced_accuracy_score(va.labels, probs.argmax(axis=1))
+        if bacc > best["bacc"] + 1e-6:
+            best["bacc"], best["state_bacc"] = bacc, snapshot()
+        if val_loss < best["loss"] - 1e-6:
+            best["loss"], best["no_improve"], best["state_loss"] = val_loss, 0, snapshot()
+        else:
+            best["no_improve"] += 1
+        history.append({"epoch": epoch, "val_auc": m["auc"], "val_bacc": bacc, "val_loss": val_loss, "probs": probs})
+        if rank == 0 and log:
+            log(f"    Epoch {epoch:03d}: Val AUROC: {m['auc']:.4f} | Val BAcc: {bacc:.4f} (best: {best['bacc']:.4f})  | "
+                f"Val Loss: {val_loss:.4f} (best: {best['loss']:.4f} ) | Epochs no improve: {best['no_improve']}/{patience}")
+        if best["no_improve"] >= patience:
+            break
+    model.encoder.grad_ready_hook = None
+    return {"best_state_bacc": best["state_bacc"], "best_state_loss": best["state_loss"], "history": history}
+
+
 # ----------------------------------------------------------------------------- patch-graph GNN
 class GraphStore:
     """Graph records resident in HBM with their normalised CSR built once (graphs are static across

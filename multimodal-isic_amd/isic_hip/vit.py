@@ -71,6 +71,14 @@ class ViTSmallEncoder(nn.Module):
         return out
 
     def load_state_dict(self, state_dict, strict=True, assign=False):
+        # a timm vit_small_patch16_224 checkpoint carries a class token: ``cls_token`` [1,1,D] and a ``pos_embed`` of
+        # tokens + 1 rows whose row 0 is the class token's position.  This encoder has no class token (the reference
+        # keeps the 196 patch latents, `save_latent.py:60`): row 0 is dropped and ``cls_token`` ignored.
+        state_dict = dict(state_dict)
+        state_dict.pop("cls_token", None)
+        pe = state_dict.get("pos_embed")
+        if pe is not None and pe.dim() == 3 and pe.shape[1] == self.tokens + 1:
+            state_dict["pos_embed"] = pe[:, 1:, :]
         missing = [n for n in self._names if n not in state_dict]
         unexpected = [k for k in state_dict if k not in self._names]
         if strict and (missing or unexpected):

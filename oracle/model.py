@@ -25,14 +25,16 @@ def sub(p, prefix):
 
 
 def milnet_forward(p, image, radiomics, offsets, emulate_bf16=False, layers=resnet.LAYERS, fusion_strategy="concat",
-                   drop=None, mil_dropout=0.0):
+                   drop=None, mil_dropout=0.0, running=None, training=True):
     """image[T,3,H,W], radiomics[B,R], offsets[B+1] -> dict like model.MultiModalMILNet.
 
-    BatchNorm always uses batch statistics (train mode).  ``drop=None``: no dropout;
+    BatchNorm uses batch statistics (``training=True``; ``running`` = encoder-relative buffer dict updated in place when
+    given) or the running statistics (``training=False``).  ``drop=None``: no dropout;
     ``drop=dict(seed, step)``: the product's counter-based train-mode dropout -- sites
     image_proj (p .3/.2, streams step*1024 + 0/1), radiomics_mlp (.4/.3, +2/3), fusion_mlp (.4, +8)
     under ``seed``; the MIL head's own site (p = mil_dropout, stream step*1024) under ``seed + 1``."""
-    feats = resnet.resnet18_features(sub(p, "encoder"), image, emulate_bf16=emulate_bf16, layers=layers)
+    feats = resnet.resnet18_features(sub(p, "encoder"), image, emulate_bf16=emulate_bf16, layers=layers,
+                                     running=running, training=training)
     mdrop = None
     fdrop = None
     if drop is not None:

@@ -63,20 +63,47 @@ def _r(x, on):
     return _RoundBF16.apply(x) if on else x
 
 
-def _bn_train(x, w, b, stats, name):
-    # batch statistics over (N,H,W), biased variance for normalisation
+def _bn_train(x, w, b, stats, name, running=None):
+    # batch statistics over (N,H,W), biased variance for normalisation; ``running``: torch BatchNorm2d's running
+    # estimates ({name}.running_mean / .running_var, momentum 0.1, UNBIASED variance) updated in place
     mean = x.mean(dim=(0, 2, 3))
     var = x.var(dim=(0, 2, 3), unbiased=False)
     if stats is not None:
         stats[name] = (mean.detach(), var.detach())
+    if running is not None:
+        n = x.numel() // x.shape[1]
+        unb = var.detach() * (n / (n - 1.0)) if n > 1 else var.detach()
+        running[f"{name}.running_mean"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mean.detach())
+        running[f"{name}.running_var"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * unb)
     inv = torch.rsqrt(var + BN_EPS)
     return (x - mean[None, :, None, None]) * (inv * w)[None, :, None, None] + b[None, :, None, None]
 
 
-def resnet18_features(p, x, emulate_bf16=False, stats=None, taps=None, layers=LAYERS):
-    """x[N,3,H,W] fp32 -> features[N,512] fp32 (train-mode BatchNorm).  ``layers`` shortens the
-    network for well-conditioned tests (default: the four ResNet-18 stages)."""
+def _bn_eval(x, w, b, running, name):
+    # y = x * scale + shift with scale = gamma * rsqrt(running_var + eps): the form isic_bn_eval_affine folds to
+    scale = w * torch.rsqrt(running[f"{name}.running_var"] + BN_EPS)
+    shift = b - running[f"{name}.running_mean"] * scale
+    return x * scale[None, :, None, None] + shift[None, :, None, None]
+
+
+def fresh_running(p):
+    """Initial BatchNorm buffers (mean 0, var 1) for every BatchNorm of the parameter dict ``p``."""
+    out = {}
+    for k, v in p.items():
+        if v.dim() == 1 and k.endswith(".weight"):
+            name = k[:-len(".weight")]
+            out[f"{name}.running_mean"] = torch.zeros_like(v)
+            out[f"{name}.running_var"] = torch.ones_like(v)
+    return out
+
+
+def resnet18_features(p, x, emulate_bf16=False, stats=None, taps=None, layers=LAYERS, running=None, training=True):
+    """x[N,3,H,W] fp32 -> features[N,512] fp32.  ``training=True``: batch-statistics BatchNorm (and the running
+    estimates in ``running`` are updated when given); ``training=False``: normalise with ``running``.  ``layers``
+    shortens the network for well-conditioned tests (default: the four ResNet-18 stages)."""
     e = emulate_bf16
+    if not training and running is None:
+        raise ValueError("eval-mode BatchNorm needs the running statistics")
 
     def conv(t, name, stride, pad):
         w = p[name]
@@ -86,7 +113,10 @@ def resnet18_features(p, x, emulate_bf16=False, stats=None, taps=None, layers=LA
 
     def cbr(t, cname, bname, stride, pad, relu=True, residual=None):
         c = conv(t, cname, stride, pad)
-        y = _bn_train(c, p[f"{bname}.weight"], p[f"{bname}.bias"], stats, bname)
+        if training:
+            y = _bn_train(c, p[f"{bname}.weight"], p[f"{bname}.bias"], stats, bname, running)
+        else:
+            y = _bn_eval(c, p[f"{bname}.weight"], p[f"{bname}.bias"], running, bname)
         if residual is not None:
             y = y + residual
         if relu:

@@ -127,10 +127,128 @@ def test_two_rank_rehearsal_of_the_bench_step_on_one_gpu(tmp_path):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2",
-           "--warmup", "1", "--bags-per-step", "2", "--patches", "4", "--image-size", "64", "--no-cpu-baseline"]
+           "--warmup", "1", "--bags-per-step", "2", "--patches", "4", "--image-size", "64", "--no-cpu-baseline", "--no-sublines"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_bags_per_step"] == 4
     assert line["value"] > 0 and line["config"]["final_loss"] == line["config"]["final_loss"]      # finite, not NaN
     assert "rehearsal" in line
+
+
+def test_bare_multi_gpu_launch_starts_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT torchrun (VERDICT r2 missing #2): the parent, which never touches the GPU,
+    starts one child per rank with the torchrun environment and relays rank 0's line -- here as the one-GPU rehearsal
+    (gloo), with the configs[3] / configs[4] sub-lines attached at toy size."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1",
+           "--bags-per-step", "2", "--patches", "4", "--image-size", "64", "--no-cpu-baseline", "--sub-steps", "2",
+           "--graphs-per-step", "8", "--images-per-step", "8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["value"] > 0
+    assert line["gnn"]["n_gpus"] == 2 and line["gnn"]["value"] > 0 and line["gnn"]["roofline"]["bound"] == "hbm"
+    assert line["vit"]["n_gpus"] == 2 and line["vit"]["value"] > 0 and line["vit"]["roofline"]["bound"] == "mfma"
+
+
+_RCCL_CHILD = r"""
+import os, sys, json
+import torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, os.path.join(root, "multimodal-isic_amd")); sys.path.insert(0, root)
+from isic_hip import ddp, optim
+from model import MultiModalMILNet
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)      # "nccl" IS RCCL on ROCm
+assert dist.get_backend() == "nccl"
+torch.manual_seed(0)
+net = MultiModalMILNet(hidden_dim=32, att_dim=16, dropout=0.0, radiomics_dim=16, num_classes=7).to(dev)
+net.train()
+opt = optim.AdamW(net.parameters(), lr=1e-3)
+flat = opt.flat
+g = torch.Generator(device=dev).manual_seed(1)
+B, K, S = 4, 3, 64
+img = torch.randn(B, K, 3, S, S, device=dev, generator=g)
+rad = torch.randn(B, 16, device=dev, generator=g)
+y = torch.arange(B, device=dev) % 7
+ddp.broadcast_parameters(flat.data)
+out = {}
+
+def backward(force, side):
+    sync = ddp.GradSync(flat.grad, world_size=1, bucket_bytes=4 << 20, force_collectives=force)
+    ddp.attach(net.encoder, flat, sync)
+    net.encoder.wgrad_stream = side
+    snaps = []
+    orig = sync.mark_ready
+    def spy(lo):
+        lo = max(0, min(int(lo), flat.numel))
+        snaps.append((lo, flat.grad[lo:].clone()))       # on the stream the hook runs on, BEFORE the collective
+        orig(lo)
+    sync.mark_ready = spy
+    opt.zero_grad(); sync.reset()
+    net.loss(net(img, rad), y).backward()
+    launched = sync.finish()
+    torch.cuda.synchronize()
+    return flat.grad.clone(), snaps, launched, len(sync.work)
+
+ref, _, _, _ = backward(False, False)
+for side in (False, True):
+    got, snaps, launched, _ = backward(True, side)
+    key = "side" if side else "main"
+    # world 1: the all-reduce is an identity, so what it leaves behind must be what backward wrote ...
+    ok_snap = all(bool(torch.equal(s, got[lo:])) for lo, s in snaps)
+    # ... and equal (up to the atomics' summation order) to a backward without any collective
+    rel = float((got - ref).norm() / ref.norm())
+    cover = sorted(launched)
+    tiled = cover[0][0] == 0 and cover[-1][1] == flat.numel and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+    out[key] = {"snapshots_equal_final": ok_snap, "rel_vs_no_collective": rel, "collectives": len(launched), "tiled": tiled}
+# the next step is unaffected: parameters update and a further backward gives finite, non-zero gradients
+opt.step(grad_scale=1.0)
+nxt, _, _, _ = backward(True, True)
+out["next_step_finite"] = bool(torch.isfinite(nxt).all()) and float(nxt.abs().sum()) > 0
+t = torch.ones(1 << 20, device=dev)
+dist.all_reduce(t)
+out["plain_allreduce_identity"] = bool((t == 1).all())
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_RESULT " + json.dumps(out), flush=True)
+"""
+
+
+def test_rccl_collectives_from_a_real_backward_world_size_1(tmp_path):
+    """RCCL on the hardware this build can reach (one GPU): a child process initialises the "nccl" (= RCCL) process group
+    with world size 1 and drives ``GradSync`` with collectives FORCED on from the real MultiModalMILNet backward, with the
+    weight gradients on the main stream and on the side stream.  World 1 makes every all-reduce an identity, so the
+    reduced buffer must equal the gradient backward wrote (snapshot at ``mark_ready``, and a backward without
+    collectives), which exercises what gloo rehearsals cannot: librccl loading, communicator creation, and the ordering
+    between the backward stream, the weight-gradient stream and RCCL's own stream.  The only RCCL evidence until the
+    driver's 8-GPU SCALE run."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "rccl_child.py"
+    script.write_text(_RCCL_CHILD)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RCCL_RESULT ")][-1][len("RCCL_RESULT "):])
+    for key in ("main", "side"):
+        assert res[key]["snapshots_equal_final"], res
+        assert res[key]["tiled"] and res[key]["collectives"] >= 3, res
+        assert res[key]["rel_vs_no_collective"] < 0.05, res      # bf16 chaos + atomics order between two backwards; a clobbered bucket reads ~1
+    assert res["next_step_finite"] and res["plain_allreduce_identity"], res

@@ -327,7 +327,8 @@ def test_encoder_backward_with_and_without_fused_bn_reductions():
     def grads(fused):
         for p in enc.parameters():
             p.grad = None
-        enc.fuse_bn_backward = fused
+        tape["fused_bn_backward"] = fused          # the mode is a property of the TAPE (recorded at forward time)
+        enc.fuse_bn_backward = not fused           # ... and the live attribute must not matter to a backward
         enc.run_backward(tape, gfeat)
         torch.cuda.synchronize()
         return {k: p.grad.detach().float().clone() for k, p in enc.named_parameters()}

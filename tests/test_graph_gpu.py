@@ -244,7 +244,9 @@ def test_gat_attention_dropout_matches_oracle():
     assert_close(pr, o["probs"], rtol=5e-5, atol=2e-6, what="gat dropout probs")
 
 
-@pytest.mark.parametrize("gtype,F_,heads", [("gatv2", 64, 4), ("gatv2", 128, 4), ("transformer", 32, 4), ("transformer", 48, 2),
+@pytest.mark.parametrize("gtype,F_,heads", [("gatv2", 64, 4), ("gatv2", 128, 4), ("gatv2", 256, 4), ("gatv2", 32, 4), ("gatv2", 96, 2),
+                                            ("gatv2", 328, 4),      # 4 x 6 register slots > 16: the per-row atomic path of d att
+                                            ("transformer", 32, 4), ("transformer", 48, 2),
                                             ("fagcn", 64, 4), ("fagcn", 96, 4)])
 def test_graphmil_edge_attention_models_vs_oracle(gtype, F_, heads):
     """GATv2Conv / TransformerConv(beta) / FAConv GraphMIL (edge_attn.hip) forward + every gradient vs the published-

@@ -233,3 +233,38 @@ def test_vit_encoder_host_surface_and_oracle():
     a, b = ov.forward_tokens(p, x), ov.forward_tokens(p, x, emulate_fp16=True)
     assert a.shape == (2, 4, 384) and float((a - b).abs().max()) < 2e-2 * float(a.abs().max())
     assert enc.flops_per_image() > 0
+    # a timm-shaped checkpoint (class token + its position row + classifier head) loads with strict=False:
+    # row 0 of pos_embed is the class token's position and is dropped, cls_token is ignored, head.* is reported
+    full = ViTSmallEncoder()
+    timm = {k: v.clone() for k, v in full.state_dict().items()}
+    pos197 = torch.randn(1, 197, 384, generator=torch.Generator().manual_seed(1))
+    timm["pos_embed"] = pos197
+    timm["cls_token"] = torch.zeros(1, 1, 384)
+    timm["head.weight"], timm["head.bias"] = torch.zeros(1000, 384), torch.zeros(1000)
+    res = full.load_state_dict(timm, strict=False)
+    assert not res.missing_keys and sorted(res.unexpected_keys) == ["head.bias", "head.weight"]
+    assert torch.equal(full.state_dict()["pos_embed"], pos197[:, 1:, :])
+    with pytest.raises(RuntimeError):
+        full.load_state_dict({**timm, "pos_embed": torch.zeros(1, 50, 384)}, strict=False)
+
+
+def test_committed_pmc_traffic_profile_matches_the_kernels():
+    """`roofline.traffic` comes from profiles/r03_pmc_traffic.json (rocprofv3 PMC passes, tools/collect_traffic.sh).
+    bench.py refuses a section stamped with other kernel sources, which silently nulled the field in BENCH_r02 -- so a
+    kernel commit that invalidates the profile must fail HERE until the profile is re-collected."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    prof = json.load(open(bench.TRAFFIC_PROFILE))
+    for section, prefixes in bench.TRAFFIC_SOURCES.items():
+        assert section in prof, f"{section}: no PMC traffic section; run tools/collect_traffic.sh on the GPU box"
+        assert prof[section]["kernel_source_hash"] == bench.kernel_source_hash(prefixes), (
+            f"{section}: kernels {prefixes} changed since the PMC traffic profile was taken; re-run "
+            f"SECTIONS={section} tools/collect_traffic.sh on the GPU box and commit profiles/r03_pmc_traffic.json")
+        assert prof[section]["hbm_bytes_per_launch"] > 0
+    # and bench.py's reader accepts it for the default workloads
+    assert bench.pmc_traffic("mil", bags_per_step=32, patches=64, image_size=224) > 0
+    assert bench.pmc_traffic("gnn", graphs_per_step=256, nodes=196, hidden=128, knn_k=8) > 0
+    assert bench.pmc_traffic("vit", images_per_step=2048, image_size=224) > 0

@@ -256,3 +256,60 @@ def test_on_device_teacher_to_graph_pipeline_matches_pickle_path():
         if k.startswith("attention_layers.") and k.endswith(".2.bias"):
             continue      # zero true gradient (softmax shift invariance): AdamW normalises atomics-order rounding noise
         assert torch.allclose(sd_a[k], sd_b[k], atol=1e-5), k
+
+
+def _image_bag_split(n_train, n_val, K, S, R, C, shift, seed):
+    """SyntheticBagImages (BASELINE.json configs[1] geometry at toy size): bf16-exact images so that the CPU oracle and
+    the HIP store (which holds bf16) see identical pixels."""
+    from dataset import SyntheticBagImages
+    ds = SyntheticBagImages(n_bags=n_train + n_val, patches=K, size=S, radiomics_dim=R, classes=C, seed=seed, shift=shift)
+    items = [ds[i] for i in range(len(ds))]
+    img = torch.stack([it["image"] for it in items]).bfloat16().float()
+    rad = torch.stack([it["radiomics"] for it in items])
+    lab = np.asarray([int(it["target"]) for it in items])
+    return (img[:n_train], rad[:n_train], lab[:n_train]), (img[n_train:], rad[n_train:], lab[n_train:])
+
+
+MILNET_AUROC_GAPS = {}      # measured |AUROC_hip - AUROC_oracle| per epoch, printed by the test (DESIGN.md section 2)
+
+
+@pytest.mark.parametrize("depth", ["two_stage", "resnet18"])
+def test_milnet_training_auroc_parity(depth):
+    """BASELINE.json metric "...; AUROC parity" for configs[1]: ``train_milnet_fold`` -- the composed
+    MultiModalMILNet (ResNet-18 encoder -> attention-MIL head -> radiomic fusion) trained end to end with the 01 loop
+    shape -- against ``oracle.train.train_milnet`` on the same synthetic split: same sampler stream, same dropout words,
+    bf16 rounding at the same points, same AdamW.  Validation AUROC (macro one-vs-rest, eval-mode BatchNorm) per epoch
+    within +-0.002 (north_star), class probabilities within 0.03, validation loss within 2 %."""
+    from isic_hip import train as T
+    from model import MultiModalMILNet
+    layers = ((64, 1), (128, 2)) if depth == "two_stage" else ((64, 1), (128, 2), (256, 2), (512, 2))
+    K, S, R, C = 4, 64, 32, 7
+    train_set, val_set = _image_bag_split(70, 63, K, S, R, C, shift=0.12, seed=11)
+    torch.manual_seed(5)
+    net = MultiModalMILNet(hidden_dim=32, att_dim=16, dropout=0.25, radiomics_dim=R, num_classes=C, encoder_layers=layers)
+    p0 = {k: v.detach().clone().float().contiguous() for k, v in net.state_dict().items()
+          if v.dtype.is_floating_point and "running_" not in k}
+    net = net.to(DEV)
+    net.set_dropout_state(seed=321, step=0)
+    epochs = 4
+    res = T.train_milnet_fold(net, train_set, val_set, lr=1e-3, weight_decay=8.6e-4, epochs=epochs, patience=100,
+                              bags_per_step=14, seed=77, num_classes=C, device=torch.device(DEV), log=None)
+    p1, running, hist = otrain.train_milnet(p0, train_set, val_set, lr=1e-3, weight_decay=8.6e-4, epochs=epochs, per_step=14,
+                                            seed=77, dropout=0.25, dropout_seed=321, layers=layers, num_classes=C)
+    gaps = [abs(a["val_auc"] - b["val_auc"]) for a, b in zip(res["history"], hist)]
+    pgaps = [float(np.abs(a["probs"] - b["probs"]).max()) for a, b in zip(res["history"], hist)]
+    MILNET_AUROC_GAPS[depth] = gaps
+    print(f"\n[milnet AUROC parity, {depth}] oracle AUROC per epoch {[round(h['val_auc'], 4) for h in hist]}  "
+          f"|dAUROC| {[round(g, 5) for g in gaps]}  max|dprob| {[round(g, 4) for g in pgaps]}")
+    assert len(res["history"]) == epochs
+    for e, (a, b) in enumerate(zip(res["history"], hist)):
+        assert abs(a["val_auc"] - b["val_auc"]) <= 0.002, (depth, e, a["val_auc"], b["val_auc"], gaps)
+        assert np.abs(a["probs"] - b["probs"]).max() < 0.03, (depth, e, pgaps)
+        assert abs(a["val_loss"] - b["val_loss"]) < 0.02 * b["val_loss"], (depth, e, a["val_loss"], b["val_loss"])
+    assert 0.6 < hist[-1]["val_auc"] < 0.995          # planted signal learnt but not saturated: the comparison is not vacuous
+    # the running BatchNorm statistics the evaluation used agree too
+    sd = net.state_dict()
+    for k, v in running.items():
+        ref = v
+        got = sd["encoder." + k].cpu()
+        assert float((got - ref).abs().max()) <= 0.02 * float(ref.abs().max()) + 1e-3, k
