@@ -375,7 +375,7 @@ def run_gnn(args, world, rank, dev):
     from isic_hip.bags import BagOffsets
     from isic_hip.graph import knn_indices
 
-    N, D, F, L, k, C = args.nodes, args.feat, args.hidden, args.gnn_layers, args.knn_k, 7
+    N, D, F, L, k, C = args.nodes, args.feat + args.node_radiomics, args.hidden, args.gnn_layers, args.knn_k, 7
     Gs = args.graphs_per_step
     n_graphs = max(2 * Gs, 512)
     torch.manual_seed(42)
@@ -392,7 +392,11 @@ def run_gnn(args, world, rank, dev):
     y = (torch.arange(n_graphs, device=dev) + rank) % C
     x = torch.randn(n_graphs, N, D, device=dev, generator=gen) + 0.25 * y.view(-1, 1, 1).float()
     offs = BagOffsets.from_lengths([N] * n_graphs, dev)
-    nn_idx = knn_indices(x.view(-1, D), offs, k).view(n_graphs, N, k)
+    nn_idx = knn_indices(x.view(-1, D), offs, k).view(n_graphs, N, k)          # edges: k-NN of the patch embeddings
+    if args.node_radiomics > 0:            # + a lesion-level radiomic vector on every node (pipeline.with_radiomic_node_features)
+        import pipeline
+        rad = torch.randn(n_graphs, args.node_radiomics, device=dev, generator=gen) + 0.25 * y.view(-1, 1).float()
+        x = pipeline.with_radiomic_node_features(x, rad)
     src = torch.arange(N, device=dev).view(1, N, 1).expand(n_graphs, N, k)
     ei = torch.stack([src.reshape(n_graphs, -1), nn_idx.reshape(n_graphs, -1)], dim=1)      # [G, 2, N*k], local ids
     records = [{"x": x[i], "edge_index": ei[i], "y": int(y[i])} for i in range(n_graphs)]
@@ -401,24 +405,63 @@ def run_gnn(args, world, rank, dev):
 
     timer = KernelTimer.get()
 
-    def step(i):
-        idx = torch.randint(0, n_graphs, (Gs,), device=dev, generator=gidx)      # drawn on the device: no host -> device copy
-        xb, ob, gb = store.batch(idx)
+    # One train step.  On one GPU the whole step (forward, autograd backward, AdamW) is captured into a hipGraph and
+    # replayed: ~50 C-ABI launches + ~30 torch kernels for ~1.3 ms of GPU work cost the host more to enqueue than the GPU
+    # to run.  The dropout stream id and Adam's step count come from a device step clock (isic_hip/graphs.py), the step's
+    # graph indices from a static tensor refilled before each replay.  Multi-GPU runs (RCCL exchange) stay eager.
+    from isic_hip import graphs as G
+    use_graph = world == 1 and not args.no_graph
+    idx_static = torch.zeros(Gs, device=dev, dtype=torch.int64)
+
+    def body():
+        xb, ob, gb = store.batch(idx_static)
         opt.zero_grad()
         sync.reset()
         probs, _ = model(xb, offsets=ob, graph=gb)
-        loss = ops.cross_entropy_from_probs(probs, store.y_dev[idx])
+        loss = ops.cross_entropy_from_probs(probs, store.y_dev[idx_static])
         loss.backward()
         sync.finish()
         opt.step(grad_scale=1.0 / world)
+        if clock is not None:
+            clock.advance()
         return loss
 
-    for i in range(2 + args.warmup):
+    def draw():
+        idx_static.copy_(torch.randint(0, n_graphs, (Gs,), device=dev, generator=gidx))   # drawn on the device
+
+    def eager_step(i):
+        draw()
+        return body()
+
+    clock = G.StepClock(dev).attach(model, opt) if use_graph else None
+    for i in range(2):
+        eager_step(i)
+    captured = G.CapturedStep(body) if use_graph else None
+
+    def step(i):
+        if captured is None:
+            return eager_step(i)
+        draw()
+        return captured.replay()
+
+    for i in range(args.warmup):
         step(i)
     elapsed, host_s, loss = timed_region(step, args, world, dev, timer, ["isic_spmm_csr_f32"], 2 + args.warmup)
     spmm = timer.stop()
     final_loss = float(loss.detach())
-    split = instrumented_pass(step, timer, dev, world, start=0)
+    measured = "HIP events inside the timed region"
+    if captured is not None:
+        # a replayed graph has no per-launch host call to bracket: the SAME step is run eagerly right after the timed
+        # region with events around every launch of the entry (a kernel runs equally long from a graph)
+        torch.cuda.synchronize()
+        timer.start(["isic_spmm_csr_f32"])
+        for i in range(args.steps):
+            eager_step(i)
+        torch.cuda.synchronize()
+        spmm = timer.stop()
+        measured = ("HIP events around every launch in an eager pass of the same steps right after the timed region "
+                    "(the timed region replays a hipGraph of the step)")
+    split = instrumented_pass(eager_step, timer, dev, world, start=0)
     if rank != 0:
         return None
     # compulsory bytes of one segmented-sum launch over the step's Gs graphs: read h + write out +
@@ -430,7 +473,8 @@ def run_gnn(args, world, rank, dev):
     achieved = Gs * per_graph * n_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     line = base_line("graphs/sec (GNN train step) @ 196-node k-NN patch graphs", "graphs/s",
                      world * Gs * args.steps / elapsed, world, args, elapsed, "f32")
-    line["config"] = {"workload": WORKLOAD_GNN, "graphs_per_step_per_gpu": Gs, "nodes": N, "feat": D, "hidden": F,
+    line["config"] = {"workload": WORKLOAD_GNN, "graphs_per_step_per_gpu": Gs, "nodes": N, "feat": D,
+                      "node_radiomics": args.node_radiomics, "hidden": F,
                       "layers": L, "knn_k": k, "parallelism": f"dp{world}",
                       "host_enqueue_ms_per_step": host_s * 1e3 / args.steps, "final_loss": final_loss}
     line["roofline"] = {
@@ -440,9 +484,10 @@ def run_gnn(args, world, rank, dev):
         "traffic": pmc_traffic("gnn", graphs_per_step=Gs, nodes=N, hidden=F, knn_k=k),
         "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1),
         "algorithmic_bytes_per_launch": Gs * per_graph, "compulsory_bytes_per_layer_per_graph": per_graph,
-        "share_of_step_time": ms * 1e-3 / elapsed, "measured": "HIP events inside the timed region",
+        "share_of_step_time": ms * 1e-3 / elapsed, "measured": measured,
     }
     line["kernel_time"] = split
+    line["config"]["step_launch"] = "hipGraph replay (device step clock)" if captured is not None else "eager"
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_gnn(model, records, args.cpu_budget_s)
     return line
@@ -557,6 +602,9 @@ def main():
     ap.add_argument("--hidden", type=int, default=128)
     ap.add_argument("--gnn-layers", type=int, default=3)
     ap.add_argument("--knn-k", type=int, default=8)
+    ap.add_argument("--node-radiomics", type=int, default=0,
+                    help="gnn: append an R-d lesion-level radiomic vector to every node's features (configs[3] 'radiomic node "
+                         "feats'; the reference's graph records carry patch embeddings only, so the default is 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wgrad-stream", action="store_true",
                     help="mil: weight gradients on a second HIP stream (A/B; off by default: concurrent kernels blur the "
@@ -568,6 +616,7 @@ def main():
                     help="multi-rank REHEARSAL for a box with one GPU: every rank uses cuda:0 and the collectives run "
                          "over gloo.  Exercises sharding, the bucketed gradient exchange fired by a real backward and the "
                          "buffer averaging; the printed rate is NOT a scaling measurement (ranks share one GPU)")
+    ap.add_argument("--no-graph", action="store_true", help="gnn: launch the step eagerly instead of replaying its hipGraph")
     ap.add_argument("--no-sublines", action="store_true",
                     help="mil: do not attach the short configs[3] (gnn) and configs[4] (vit) runs to the line")
     ap.add_argument("--sub-steps", type=int, default=20, help="timed steps of each attached sub-benchmark")

@@ -56,9 +56,24 @@ const char* isic_target_arch(void);
  * transA/transB: 0 = stored [rows, K] / [K, cols]; 1 = stored transposed. */
 int isic_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                   float* C, int ldc, const float* bias, int act, float beta, void* stream);
+/* The same product with a caller-owned workspace (isic_gemm_f32_workspace_bytes(...) bytes, 16-byte aligned; may be
+ * NULL / 0).  Large products (>= 1e8 multiply-adds, every dimension a multiple of 4 floats, 16-byte aligned operands)
+ * run on a persistent LDS-DMA-staged 256 x 128 x 32 kernel; a long reduction into a small output (the weight gradients
+ * dW = dY^T X over all the nodes of a step) is split over K with the partial tiles parked in the workspace and added in
+ * split order -- bit-reproducible.  Without a workspace such a product runs unsplit (or, on the small-tile kernel, with
+ * fp32 atomics in arrival order). */
+size_t isic_gemm_f32_workspace_bytes(int transA, int transB, int M, int N, int K);
+int isic_gemm_f32_ws(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                     float* C, int ldc, const float* bias, int act, float beta, void* workspace, size_t workspace_bytes,
+                     void* stream);
 
 /* out[n] = sum_m X[m,n] (+ beta*out): bias gradients of the layers above. */
 int isic_colsum_f32(const float* X, int M, int N, int ldx, float* out, float beta, void* stream);
+/* ... with a workspace (isic_colsum_f32_workspace_bytes(M, N) bytes; may be NULL / 0): the row chunks of a tall matrix
+ * are then added in chunk order instead of through fp32 atomics -- bit-reproducible. */
+size_t isic_colsum_f32_workspace_bytes(int M, int N);
+int isic_colsum_f32_ws(const float* X, int M, int N, int ldx, float* out, float beta, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* y = act'(...) helpers for backward: dx = dy * (1 - t*t)  (tanh, from its output t). */
 int isic_tanh_bwd_f32(const float* dy, const float* t, float* dx, int64_t n, void* stream);
@@ -69,6 +84,17 @@ int isic_tanh_bwd_f32(const float* dy, const float* t, float* dx, int64_t n, voi
 int isic_relu_dropout_fwd_f32(float* x, int64_t n, uint32_t drop_threshold, float drop_scale, uint64_t seed,
                               uint64_t stream_id, void* stream);
 int isic_relu_dropout_bwd_f32(const float* y, float* dy, int64_t n, float drop_scale, void* stream);
+
+/* ------------------------------------------------------------------ device step clock (captured train steps)
+ * A train step captured into a hipGraph replays the SAME kernel arguments, but two values must change from step to
+ * step: the dropout stream id (step * 1024 + site, oracle/philox.py) and Adam's step count t.  The `_clk` forms of the
+ * entries that consume them take a device pointer to  clock[2] = {dropout step, optimizer steps taken}  and form
+ * stream = stream_id + clock[0] * 1024  /  t = clock[1] + 1  on the device; isic_step_clock_advance is the last
+ * kernel of the step.  With clock == NULL they are the plain entries.  (Reference loop being captured:
+ * 05_train_gnns.py:336-346 / 01_train_mil_teacher.py:237-246.) */
+int isic_step_clock_advance(uint64_t* clock, int dropout_steps, int optimizer_steps, void* stream);
+int isic_relu_dropout_fwd_clk_f32(float* x, int64_t n, uint32_t drop_threshold, float drop_scale, uint64_t seed,
+                                  uint64_t stream_id, const uint64_t* clock, void* stream);
 
 /* ------------------------------------------------------------------ attention pool over variable-length bags
  * One workgroup per bag / graph; bags given CSR-style by offsets[B+1] into the
@@ -112,6 +138,14 @@ int isic_layernorm_fwd(const float* x, const float* gamma, const float* beta, co
 int isic_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
                        const float* rstd, float* dx, float* dgamma, float* dbeta, int M, int N, int relu,
                        uint32_t drop_threshold, float drop_scale, uint64_t seed, uint64_t stream_id, void* stream);
+/* ... with the dropout step taken from a device step clock (see "device step clock" above; clock may be NULL) */
+int isic_layernorm_fwd_clk(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                           float* mean, float* rstd, int M, int N, float eps, int relu, uint32_t drop_threshold,
+                           float drop_scale, uint64_t seed, uint64_t stream_id, const uint64_t* clock, void* stream);
+int isic_layernorm_bwd_clk(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
+                           const float* rstd, float* dx, float* dgamma, float* dbeta, int M, int N, int relu,
+                           uint32_t drop_threshold, float drop_scale, uint64_t seed, uint64_t stream_id,
+                           const uint64_t* clock, void* stream);
 
 /* y = x / max(||x||_2, eps) per row and its backward: F.normalize of
  * SAGEConv(normalize=True) (05_train_gnns.py:87-88). */
@@ -141,6 +175,10 @@ int isic_softmax_rows_bwd(const float* probs, const float* d_probs, float* d_log
 int isic_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float step_size, float beta1, float beta2,
                    float eps, float decay_factor, float l2, float bias_correction2_sqrt, float grad_scale,
                    uint16_t* p_bf16, void* stream);
+/* ... with t = clock[1] + 1 read on the device: step_size = lr / (1 - beta1^t), bias_correction2_sqrt = sqrt(1 - beta2^t) */
+int isic_adam_step_clk(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                       float eps, float decay_factor, float l2, float grad_scale, uint16_t* p_bf16, const uint64_t* clock,
+                       void* stream);
 
 /* ------------------------------------------------------------------ patch-graph adjacency + message passing
  * k-NN graph on node features (03_build_graphs.py:37-54, utils_g_mil.py:596-615):
@@ -266,16 +304,20 @@ int isic_gat_bwd(const float* dout, const float* xp, const float* alpha, const f
  *   forward: up = stride, down = 1, pad = padding, w = bf16 W[co][kh][kw][ci]
  *   dgrad:   up = 1, down = stride, pad = k-1-padding, in = dY, w = W flipped+transposed [ci][kh][kw][co]
  * Optional fused BatchNorm statistics (down = 1 only): per-channel sum / sum of squares of the
- * rounded outputs are ADDED (fp64 atomics) into stat_sum/stat_sumsq[stat_slots][Cout] (zeroed by
- * the caller; isic_bn_finalize sums the slots).
+ * rounded outputs are ADDED into row (block % stat_slots) of stat_sum/stat_sumsq[stat_slots][Cout] (zeroed by
+ * the caller; isic_bn_finalize adds the rows in a fixed order).  The ResNet-18 kernels (3x3 stride 1 with >= 64
+ * channels, stride-2 3x3, 1x1) are persistent with at most one block per CU: with stat_slots >= 256 every block owns
+ * its row and the statistics are bit-reproducible; fewer rows (or the generic tile-per-block kernel) share rows
+ * through fp64 atomics in arrival order.
  * Cin and Cout must be multiples of 64; down in {1,2}. */
 int isic_conv2d_igemm_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int Hin, int Win, int Cin,
                            int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad,
                            const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots, void* stream);
 /* dW[co][kh][kw][ci] (fp32) += sum_{n,ho,wo} dY[n,ho,wo,co] * X[n,ho*stride+kh-pad,wo*stride+kw-pad,ci]
- * (accumulates into the caller's zeroed or running gradient with whole-row fp32 atomics).
- * workspace: 256-byte aligned, isic_conv2d_wgrad_workspace_bytes(...) bytes (per-pixel
- * source-offset table, rebuilt by every call). */
+ * (accumulates into the caller's zeroed or running gradient; no atomics: blocks write split-K partial tiles into the
+ * workspace and a second kernel adds them in a fixed order -- every weight gradient is bit-reproducible).
+ * workspace: 256-byte aligned, isic_conv2d_wgrad_workspace_bytes(...) bytes (per-pixel source-offset table rebuilt by
+ * every call + the split-K partials). */
 size_t isic_conv2d_wgrad_workspace_bytes(int N, int Cin, int Hout, int Wout, int Cout, int Kh, int Kw);
 int isic_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dw, int N, int Hin, int Win, int Cin,
                            int Hout, int Wout, int Cout, int Kh, int Kw, int stride, int pad, void* workspace,
@@ -312,18 +354,24 @@ int isic_conv_stem_fwd_bf16(const uint16_t* in_nhwc4, const uint16_t* w_stem, ui
 int isic_conv_stem_fwd_stats_bf16(const uint16_t* in_nhwc4, const uint16_t* w_stem, uint16_t* out, int N, int Hin,
                                   int Win, int Hout, int Wout, double* stat_sum, double* stat_sumsq, int stat_slots,
                                   void* stream);
+/* dw[64][7][7][3] (fp32) += weight gradient of the stem.  No atomics: every persistent block leaves its partial in
+ * `workspace` (isic_conv_stem_wgrad_workspace_bytes() bytes, 256-byte aligned) and a second kernel adds the partials in
+ * block order -- bit-reproducible. */
+size_t isic_conv_stem_wgrad_workspace_bytes(void);
 int isic_conv_stem_wgrad_bf16(const uint16_t* in_nhwc4, const uint16_t* dy, float* dw, int N, int Hin, int Win,
-                              int Hout, int Wout, void* stream);
+                              int Hout, int Wout, void* workspace, size_t workspace_bytes, void* stream);
 int isic_conv_stem_pack_bf16(const float* w_krsc, uint16_t* w_stem, void* stream);
 /* Stem weight gradient straight from the POOLED gradient: dw += conv_wgrad(in, dY) with
  * dY = BatchNorm(+ReLU) backward (isic_bn_bwd_apply_pooled_bf16) of the 3x3/2 max-pool backward of dy_pooled, formed in
  * registers from y0 (the stem convolution output), argmax and the reduced sums dgamma / dbeta -- the full-size dY is
- * neither written nor read.  Also adds dgamma / dbeta into the fp32 gradients when those are given.  Hp, Wp: pooled size. */
+ * neither written nor read.  Also adds dgamma / dbeta into the fp32 gradients when those are given.  Hp, Wp: pooled size.
+ * workspace: isic_conv_stem_wgrad_workspace_bytes() bytes (per-block partials, added in block order: no atomics). */
 int isic_conv_stem_wgrad_bn_pooled_bf16(const uint16_t* in_nhwc4, const uint16_t* y0, const uint8_t* argmax,
                                         const uint16_t* dy_pooled, const float* mean, const float* rstd,
                                         const float* gamma, const float* scale, const float* shift, const double* dgamma,
                                         const double* dbeta, float* dw, float* dgamma_f32, float* dbeta_f32, int N,
-                                        int Hin, int Win, int Hout, int Wout, int Hp, int Wp, void* stream);
+                                        int Hin, int Win, int Hout, int Wout, int Hp, int Wp, void* workspace,
+                                        size_t workspace_bytes, void* stream);
 /* NCHW fp32/bf16 images (the reference's dataset layout, dataset.py:36-40) ->
  * NHWC bf16 with C padded to 4. */
 int isic_nchw_to_nhwc4_bf16(const void* in, int in_is_bf16, uint16_t* out, int N, int C, int H, int W, void* stream);

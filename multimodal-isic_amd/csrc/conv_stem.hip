@@ -26,6 +26,8 @@ constexpr int PROW = PC * 8;               // bytes per patch row (4 bf16 per pi
 constexpr int WROW = 7 * 64 + 16;          // bytes per co row of the LDS weight image (padded: conflict-free)
 constexpr int CPAD = 72;                   // epilogue row stride (elements)
 constexpr int YROW = 128 + 32;             // bytes per pixel row of the staged dY tile
+constexpr int STEM_DW_ELEMS = 64 * 7 * 7 * 3;   // the weight gradient, [co][kh][kw][c]
+constexpr int STEM_WGRAD_BLOCKS = 512;     // persistent blocks of the weight-gradient kernels (one partial each)
 
 struct StemArgs {
   const unsigned short* in;   // [N,Hin,Win,4]
@@ -267,7 +269,9 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(StemArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = i * 16 + fg * 4 + r;
-        atomicAdd(a.dw + ((co * 7 + kh) * 7 + kw) * 3 + c, acc[i][j][r]);
+        // the block's OWN partial (workspace [grid][64*7*7*3]); stem_wgrad_reduce_kernel adds them in block order:
+        // deterministic, where fp32 atomics added the blocks in arrival order
+        a.dw[(size_t)blockIdx.x * STEM_DW_ELEMS + ((co * 7 + kh) * 7 + kw) * 3 + c] = acc[i][j][r];
       }
     }
 }
@@ -433,9 +437,25 @@ __global__ __launch_bounds__(256, 2) void conv_stem_wgrad_bn_kernel(StemBnArgs b
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = i * 16 + fg * 4 + r;
-        atomicAdd(a.dw + ((co * 7 + kh) * 7 + kw) * 3 + c, acc[i][j][r]);
+        // the block's OWN partial (workspace [grid][64*7*7*3]); stem_wgrad_reduce_kernel adds them in block order:
+        // deterministic, where fp32 atomics added the blocks in arrival order
+        a.dw[(size_t)blockIdx.x * STEM_DW_ELEMS + ((co * 7 + kh) * 7 + kw) * 3 + c] = acc[i][j][r];
       }
     }
+}
+
+// dw[e] += sum over the blocks' partials, in block order: 16 lanes per element (lane g takes blocks g, g + 16, ...) joined
+// by a fixed xor tree
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                 int nparts) {
+  const int g = threadIdx.x & 15;
+  const int e = blockIdx.x * 16 + (threadIdx.x >> 4);
+  float v = 0.f;
+  if (e < STEM_DW_ELEMS)
+    for (int s = g; s < nparts; s += 16) v += partial[(size_t)s * STEM_DW_ELEMS + e];
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+  if (e < STEM_DW_ELEMS && g == 0) dw[e] += v;
 }
 
 // fp32 [64][7][7][3] (channels_last memory of the OIHW parameter) -> bf16 [64][7][8][4], zero padded
@@ -483,16 +503,21 @@ int isic_conv_stem_fwd_stats_bf16(const uint16_t* in_nhwc4, const uint16_t* w_st
   return isic_launch_status();
 }
 
+size_t isic_conv_stem_wgrad_workspace_bytes(void) { return (size_t)STEM_WGRAD_BLOCKS * STEM_DW_ELEMS * sizeof(float); }
+
 int isic_conv_stem_wgrad_bf16(const uint16_t* in_nhwc4, const uint16_t* dy, float* dw, int N, int Hin, int Win,
-                              int Hout, int Wout, void* stream) {
-  ISIC_CHECK_ARG(in_nhwc4 && dy && dw && N > 0 && Hin > 0 && Win > 0);
+                              int Hout, int Wout, void* workspace, size_t workspace_bytes, void* stream) {
+  ISIC_CHECK_ARG(in_nhwc4 && dy && dw && workspace && N > 0 && Hin > 0 && Win > 0);
+  if (workspace_bytes < isic_conv_stem_wgrad_workspace_bytes()) return ISIC_ERR_WORKSPACE;
   StemArgs a;
   a.stat_sum = nullptr; a.stat_sumsq = nullptr; a.stat_slots = 1;
-  a.in = in_nhwc4; a.w = nullptr; a.out = nullptr; a.dy = dy; a.dw = dw;
+  a.in = in_nhwc4; a.w = nullptr; a.out = nullptr; a.dy = dy; a.dw = reinterpret_cast<float*>(workspace);
   int rc = stem_args(a, N, Hin, Win, Hout, Wout);
   if (rc != ISIC_OK) return rc;
-  const int grid = a.total_tiles < 512 ? a.total_tiles : 512;
+  const int grid = a.total_tiles < STEM_WGRAD_BLOCKS ? a.total_tiles : STEM_WGRAD_BLOCKS;
   hipLaunchKernelGGL(conv_stem_wgrad_kernel, dim3(grid), dim3(256), 0, as_stream(stream), a);
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(ceil_div(STEM_DW_ELEMS, 16)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const float*>(workspace), dw, grid);
   return isic_launch_status();
 }
 
@@ -500,21 +525,26 @@ int isic_conv_stem_wgrad_bn_pooled_bf16(const uint16_t* in_nhwc4, const uint16_t
                                         const uint16_t* dy_pooled, const float* mean, const float* rstd,
                                         const float* gamma, const float* scale, const float* shift, const double* dgamma,
                                         const double* dbeta, float* dw, float* dgamma_f32, float* dbeta_f32, int N,
-                                        int Hin, int Win, int Hout, int Wout, int Hp, int Wp, void* stream) {
+                                        int Hin, int Win, int Hout, int Wout, int Hp, int Wp, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
   ISIC_CHECK_ARG(in_nhwc4 && y0 && argmax && dy_pooled && mean && rstd && gamma && scale && shift && dgamma && dbeta && dw);
+  ISIC_CHECK_ARG(workspace != nullptr);
+  if (workspace_bytes < isic_conv_stem_wgrad_workspace_bytes()) return ISIC_ERR_WORKSPACE;
   ISIC_CHECK_ARG(N > 0 && Hin > 0 && Win > 0 && (dgamma_f32 == nullptr) == (dbeta_f32 == nullptr));
   ISIC_CHECK_ARG(Hp == (Hout + 2 - 3) / 2 + 1 && Wp == (Wout + 2 - 3) / 2 + 1);
   StemBnArgs b;
   StemArgs& a = b.s;
   a.stat_sum = nullptr; a.stat_sumsq = nullptr; a.stat_slots = 1;
-  a.in = in_nhwc4; a.w = nullptr; a.out = nullptr; a.dy = nullptr; a.dw = dw;
+  a.in = in_nhwc4; a.w = nullptr; a.out = nullptr; a.dy = nullptr; a.dw = reinterpret_cast<float*>(workspace);
   int rc = stem_args(a, N, Hin, Win, Hout, Wout);
   if (rc != ISIC_OK) return rc;
   b.y0 = y0; b.argmax = argmax; b.gp = dy_pooled; b.mean = mean; b.rstd = rstd; b.gamma = gamma; b.scale = scale;
   b.shift = shift; b.dgamma = dgamma; b.dbeta = dbeta; b.dgamma_f32 = dgamma_f32; b.dbeta_f32 = dbeta_f32;
   b.Hp = Hp; b.Wp = Wp;
-  const int grid = a.total_tiles < 512 ? a.total_tiles : 512;
+  const int grid = a.total_tiles < STEM_WGRAD_BLOCKS ? a.total_tiles : STEM_WGRAD_BLOCKS;
   hipLaunchKernelGGL(conv_stem_wgrad_bn_kernel, dim3(grid), dim3(256), 0, as_stream(stream), b);
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(ceil_div(STEM_DW_ELEMS, 16)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const float*>(workspace), dw, grid);
   return isic_launch_status();
 }
 

@@ -22,8 +22,10 @@
 //                   64x64 tile (4x4 MFMA tiles each, same LDS-read : MFMA ratio as above) and split
 //                   the 128-pixel K-tile four ways.
 // The pixel range is additionally split over blockIdx.y; a block's partial tile is transposed through
-// LDS (and, with KSPLIT, summed over its four waves there) and added to the caller's gradient as whole
-// 256-byte rows, one fp32 atomic wave-instruction per row.
+// LDS (and, with KSPLIT, summed over its four waves there) and written as whole 256-byte rows into ITS OWN slice of
+// the workspace ([split][Cout][Kh][Kw][Cin]); wgrad_reduce_kernel then adds the slices to the caller's gradient in
+// split order.  DETERMINISTIC (round 3): the fp32 row atomics this replaces added the splits in arrival order, so two
+// identical steps gave different last bits in 6 of ResNet-18's 20 weight gradients.
 #include "common.h"
 
 namespace {
@@ -31,7 +33,8 @@ namespace {
 struct WgradArgs {
   const unsigned short* x;
   const unsigned short* dy;
-  float* dw;           // [Cout][Kh][Kw][Cin] fp32, accumulated into
+  float* dw;           // split-K partials [splits][Cout][Kh][Kw][Cin] fp32 (workspace), overwritten
+  size_t split_stride; // Cout*Kh*Kw*Cin
   const int2* tab;     // [M] : .x = ((n*Hin + ho*s - p)*Win + wo*s - p)*Cin, .y = ho << 16 | wo
   int N, Hin, Win, Cin, Hout, Wout, Cout, Kh, Kw, stride, pad;
   int M;               // N*Hout*Wout
@@ -218,23 +221,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   __syncthreads();
   const size_t row_stride = (size_t)a.Kh * a.Kw * a.Cin;
   const float* C0 = reinterpret_cast<const float*>(smem);
+  float* part = a.dw + (size_t)blockIdx.y * a.split_stride;      // every (tile, split) block writes its whole tile
   if (KSPLIT) {
     for (int rr = 0; rr < 16; ++rr) {
       const int row = wave * 16 + rr;
       const float v = (C0[row * 64 + lane] + C0[4096 + row * 64 + lane]) + (C0[8192 + row * 64 + lane] + C0[12288 + row * 64 + lane]);
-      atomicAdd(a.dw + (size_t)(co0 + row) * row_stride + (size_t)tap * a.Cin + ci0 + lane, v);
+      part[(size_t)(co0 + row) * row_stride + (size_t)tap * a.Cin + ci0 + lane] = v;
     }
   } else {
     for (int row = 0; row < 64; ++row)
-      atomicAdd(a.dw + (size_t)(co0 + wm * 64 + row) * row_stride + (size_t)tap * a.Cin + ci0 + wn * 64 + lane,
-                Ct[row * 64 + lane]);
+      part[(size_t)(co0 + wm * 64 + row) * row_stride + (size_t)tap * a.Cin + ci0 + wn * 64 + lane] = Ct[row * 64 + lane];
   }
+}
+
+// dw[e] += sum over the splits of partial[s][e], in split order.  G lanes per element share the splits (lane g takes
+// s = g, g + G, ...) and meet in a fixed xor tree: the order never depends on timing.
+template <int G>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                            int splits, size_t elems) {
+  const int g = threadIdx.x % G;
+  const size_t e = (size_t)blockIdx.x * (256 / G) + threadIdx.x / G;
+  float v = 0.f;
+  if (e < elems)
+    for (int s = g; s < splits; s += G) v += partial[(size_t)s * elems + e];
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+  if (e < elems && g == 0) dw[e] += v;
 }
 
 struct WgradPlan {
   bool big;
   int tiles, splits, ktiles, ktiles_per_split;
-  size_t table_bytes;
+  size_t table_bytes, partial_bytes, elems;
 };
 
 WgradPlan wgrad_plan(int N, int Cin, int Hout, int Wout, int Cout, int Kh, int Kw) {
@@ -252,6 +270,8 @@ WgradPlan wgrad_plan(int N, int Cin, int Hout, int Wout, int Cout, int Kh, int K
   p.ktiles_per_split = ceil_div(p.ktiles, splits);
   p.splits = ceil_div(p.ktiles, p.ktiles_per_split);
   p.table_bytes = ((size_t)M * sizeof(int2) + 255) / 256 * 256;
+  p.elems = (size_t)Cout * Kh * Kw * Cin;
+  p.partial_bytes = (size_t)p.splits * p.elems * sizeof(float);
   return p;
 }
 
@@ -278,7 +298,7 @@ extern "C" {
 size_t isic_conv2d_wgrad_workspace_bytes(int N, int Cin, int Hout, int Wout, int Cout, int Kh, int Kw) {
   if (N <= 0 || Cin <= 0 || Hout <= 0 || Wout <= 0 || Cout <= 0 || Kh <= 0 || Kw <= 0) return 0;
   const WgradPlan p = wgrad_plan(N, Cin, Hout, Wout, Cout, Kh, Kw);
-  size_t need = p.table_bytes + 256;
+  size_t need = p.table_bytes + p.partial_bytes + 256;
   if (Cin == 64 && Cout == 64 && Kh == 3 && Kw == 3) {   // stride 1 / pad 1: input size = output size
     const size_t c64 = isic_wgrad_c64_workspace_bytes(N, Hout, Wout);
     if (c64 > need) need = c64;
@@ -319,9 +339,10 @@ int isic_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dw, int
     }
   }
   const WgradPlan p = wgrad_plan(N, Cin, Hout, Wout, Cout, Kh, Kw);
-  if (workspace_bytes < p.table_bytes) return ISIC_ERR_WORKSPACE;
+  if (workspace_bytes < p.table_bytes + p.partial_bytes) return ISIC_ERR_WORKSPACE;
   WgradArgs a;
-  a.x = x; a.dy = dy; a.dw = dw; a.tab = reinterpret_cast<const int2*>(workspace);
+  float* partial = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + p.table_bytes);
+  a.x = x; a.dy = dy; a.dw = partial; a.split_stride = p.elems; a.tab = reinterpret_cast<const int2*>(workspace);
   a.N = N; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
   a.Kh = Kh; a.Kw = Kw; a.stride = stride; a.pad = pad;
   a.M = (int)M64;
@@ -334,6 +355,12 @@ int isic_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dw, int
   dim3 grid(p.tiles, p.splits);
   if (p.big) hipLaunchKernelGGL((conv_wgrad_kernel<false>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((conv_wgrad_kernel<true>), grid, dim3(256), 0, s, a);
+  if (p.splits > 32)
+    hipLaunchKernelGGL((wgrad_reduce_kernel<16>), dim3((unsigned)ceil_div64((int64_t)p.elems, 16)), dim3(256), 0, s, partial, dw,
+                       p.splits, p.elems);
+  else
+    hipLaunchKernelGGL((wgrad_reduce_kernel<4>), dim3((unsigned)ceil_div64((int64_t)p.elems, 64)), dim3(256), 0, s, partial, dw,
+                       p.splits, p.elems);
   return isic_launch_status();
 }
 

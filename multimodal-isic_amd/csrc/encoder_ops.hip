@@ -59,16 +59,24 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const unsigned short* __r
   block_reduce_to_global<2>(acc, C, dst);
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ sum, const double* __restrict__ sumsq, int nslots,
+// 16 lanes per channel: lane sl adds the slot rows sl, sl + 16, ... (the producing convolutions leave one row per block:
+// up to 256, the stem 1024), then a fixed xor tree joins the 16 partial sums -- a fixed order, so the result does not
+// depend on which block finished first, and the 256-1024 dependent loads of a one-thread-per-channel loop are gone.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ sum, const double* __restrict__ sumsq,
+                                                           int nslots,
                                    int64_t rows, int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ scale, float* __restrict__ shift,
                                    float* __restrict__ mean_o, float* __restrict__ rstd_o,
                                    float* __restrict__ running_mean, float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int sl = threadIdx.x & 15;
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
   const double n = (double)rows;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < nslots; ++k) { s1 += sum[(size_t)k * C + c]; s2 += sumsq[(size_t)k * C + c]; }
+  if (c < C)
+    for (int k = sl; k < nslots; k += 16) { s1 += sum[(size_t)k * C + c]; s2 += sumsq[(size_t)k * C + c]; }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 16); s2 += __shfl_xor(s2, o, 16); }
+  if (c >= C || sl != 0) return;
   const double mean = s1 / n;
   double var = s2 / n - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -90,10 +98,14 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sum, const double*
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ s_dz, const double* __restrict__ s_dzy, int nslots, int C,
                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                        double* __restrict__ dgamma, double* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int sl = threadIdx.x & 15;                                  // 16 lanes per channel, fixed xor tree (bn_finalize_kernel)
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
   double a = 0.0, b = 0.0;
-  for (int s = 0; s < nslots; ++s) { a += s_dz[(size_t)s * C + c]; b += s_dzy[(size_t)s * C + c]; }
+  if (c < C)
+    for (int s = sl; s < nslots; s += 16) { a += s_dz[(size_t)s * C + c]; b += s_dzy[(size_t)s * C + c]; }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 16); b += __shfl_xor(b, o, 16); }
+  if (c >= C || sl != 0) return;
   dbeta[c] = a;
   dgamma[c] = (double)rstd[c] * (b - (double)mean[c] * a);
 }
@@ -624,7 +636,7 @@ int isic_bn_finalize(const double* sum, const double* sumsq, int nslots, int64_t
                      float* rstd, float* running_mean, float* running_var, void* stream) {
   ISIC_CHECK_ARG(sum && sumsq && gamma && beta && scale && shift && mean && rstd && rows > 0 && C > 0 && nslots > 0);
   ISIC_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, as_stream(stream), sum, sumsq, nslots,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, as_stream(stream), sum, sumsq, nslots,
                      rows, C,
                      gamma, beta, eps, momentum, scale, shift, mean, rstd, running_mean, running_var);
   return isic_launch_status();
@@ -633,7 +645,7 @@ int isic_bn_finalize(const double* sum, const double* sumsq, int nslots, int64_t
 int isic_bn_bwd_finalize(const double* sum_dz, const double* sum_dzy, int nslots, int C, const float* mean,
                          const float* rstd, double* dgamma, double* dbeta, void* stream) {
   ISIC_CHECK_ARG(sum_dz && sum_dzy && mean && rstd && dgamma && dbeta && nslots > 0 && C > 0);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, as_stream(stream), sum_dz, sum_dzy, nslots,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, as_stream(stream), sum_dz, sum_dzy, nslots,
                      C, mean, rstd, dgamma, dbeta);
   return isic_launch_status();
 }

@@ -12,6 +12,12 @@
 // both operands use it).
 #include "common.h"
 
+// persistent LDS-DMA kernel for the large products (gemm_f32p.hip); ISIC_ERR_UNSUPPORTED = "not for this shape"
+size_t isic_gemm_f32p_workspace_bytes(int transA, int transB, int M, int N, int K);
+int isic_gemm_f32p_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                          float* C, int ldc, const float* bias, int act, float beta, void* workspace,
+                          size_t workspace_bytes, hipStream_t stream);
+
 namespace {
 
 constexpr int BM = 64, BN = 64, BK = 16, LDT = BK + 4;  // 80-byte rows: 16-B aligned, conflict-light
@@ -165,9 +171,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
 // thread; LDS tree over the row lanes, one atomic per column and block into the pre-scaled output.  FEW, FAT blocks:
 // same-address atomics retire at ~3 ns each per cache line (measured: 392 blocks x 128 columns took 41 us, all of it
 // atomics), so the grid is ~96 blocks of 16 waves, not one block per 128 rows.
+// With `partial` (workspace [gridDim.y][N]) a block stores its chunk sums there and colsum_reduce_kernel adds the chunks in
+// order: bit-reproducible.  Without a workspace the chunks meet through fp32 atomics in arrival order.
 template <int VGB>
 __global__ __launch_bounds__(1024) void colsum4_kernel(const float* __restrict__ X, int M, int N, int ldx,
-                                                       float* __restrict__ out, int rows_per_block) {
+                                                       float* __restrict__ out, int rows_per_block,
+                                                       float* __restrict__ partial) {
   constexpr int RL = 1024 / VGB;
   __shared__ f32x4 part[1024];
   const int vg = threadIdx.x % VGB, rl = threadIdx.x / VGB;
@@ -192,9 +201,22 @@ __global__ __launch_bounds__(1024) void colsum4_kernel(const float* __restrict__
     f32x4 t = part[vg];
 #pragma unroll
     for (int k = 1; k < RL; ++k) t += part[k * VGB + vg];
+    if (partial) {
+      *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.y * N + col) = t;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(out + col + e, t[e]);
+      for (int e = 0; e < 4; ++e) atomicAdd(out + col + e, t[e]);
+    }
   }
+}
+
+// out[n] = beta * out[n] + sum over the chunks, in chunk order
+__global__ void colsum_reduce_kernel(const float* __restrict__ partial, int chunks, int N, float* __restrict__ out, float beta) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += partial[(size_t)c * N + n];
+  out[n] = beta != 0.f ? beta * out[n] + s : s;
 }
 
 __global__ void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ t, float* __restrict__ dx,
@@ -208,7 +230,9 @@ __global__ void tanh_bwd_kernel(const float* __restrict__ dy, const float* __res
 }
 
 __global__ void relu_dropout_fwd_kernel(float* __restrict__ x, int64_t n, unsigned int thr, float scale,
-                                        unsigned long long seed, unsigned long long stream_id) {
+                                        unsigned long long seed, unsigned long long stream_id,
+                                        const unsigned long long* __restrict__ clock) {
+  if (clock) stream_id += clock[0] * 1024ULL;              // device step clock (captured graphs)
   // each thread handles one Philox block = 4 consecutive elements
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nb = (n + 3) >> 2, stride = (int64_t)gridDim.x * blockDim.x;
@@ -245,13 +269,28 @@ inline int grid_for(int64_t n, int block) {
 
 extern "C" {
 
+size_t isic_gemm_f32_workspace_bytes(int transA, int transB, int M, int N, int K) {
+  return isic_gemm_f32p_workspace_bytes(transA, transB, M, N, K);
+}
+
 int isic_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                   float* C, int ldc, const float* bias, int act, float beta, void* stream) {
+  return isic_gemm_f32_ws(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, beta, nullptr, 0, stream);
+}
+
+int isic_gemm_f32_ws(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                     float* C, int ldc, const float* bias, int act, float beta, void* workspace, size_t workspace_bytes,
+                     void* stream) {
   ISIC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0);
   if (M == 0 || N == 0) return ISIC_OK;
   ISIC_CHECK_ARG(A && B && C);
   ISIC_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N);
   ISIC_CHECK_ARG(act >= ISIC_ACT_NONE && act <= ISIC_ACT_TANH);
+  {
+    const int rc = isic_gemm_f32p_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, beta, workspace,
+                                         workspace_bytes, as_stream(stream));
+    if (rc != ISIC_ERR_UNSUPPORTED) return rc;             // launched (or failed for real): large, 16-byte friendly products
+  }
   GemmArgs a;
   a.A = A; a.B = B; a.C = C; a.bias = bias;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
@@ -283,7 +322,17 @@ int isic_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, i
   return isic_launch_status();
 }
 
+size_t isic_colsum_f32_workspace_bytes(int M, int N) {
+  if (M < 1024 || N <= 0 || N % 4 != 0) return 0;
+  return (size_t)96 * N * sizeof(float) + 256;             // at most 96 row chunks (colsum4_kernel's launch shape)
+}
+
 int isic_colsum_f32(const float* X, int M, int N, int ldx, float* out, float beta, void* stream) {
+  return isic_colsum_f32_ws(X, M, N, ldx, out, beta, nullptr, 0, stream);
+}
+
+int isic_colsum_f32_ws(const float* X, int M, int N, int ldx, float* out, float beta, void* workspace,
+                       size_t workspace_bytes, void* stream) {
   ISIC_CHECK_ARG(M >= 0 && N >= 0 && ldx >= N);
   if (N == 0) return ISIC_OK;
   ISIC_CHECK_ARG(X && out);
@@ -297,11 +346,18 @@ int isic_colsum_f32(const float* X, int M, int N, int ldx, float* out, float bet
     if (chunks4 < 1) chunks4 = 1;
     const int rpb = ceil_div(M, chunks4);
     chunks4 = ceil_div(M, rpb);
-    hipLaunchKernelGGL(gemm_scale_kernel, dim3(1), dim3(256), 0, as_stream(stream), out, 1, N, N, beta);
+    float* partial = nullptr;                                      // deterministic path: chunk sums parked in the workspace
+    if (workspace && workspace_bytes >= (size_t)chunks4 * N * sizeof(float) && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0)
+      partial = reinterpret_cast<float*>(workspace);
+    if (!partial)
+      hipLaunchKernelGGL(gemm_scale_kernel, dim3(1), dim3(256), 0, as_stream(stream), out, 1, N, N, beta);
     const dim3 grid(colblocks4, chunks4);
-    if (vgb == 64) hipLaunchKernelGGL(colsum4_kernel<64>, grid, dim3(1024), 0, as_stream(stream), X, M, N, ldx, out, rpb);
-    else if (vgb == 32) hipLaunchKernelGGL(colsum4_kernel<32>, grid, dim3(1024), 0, as_stream(stream), X, M, N, ldx, out, rpb);
-    else hipLaunchKernelGGL(colsum4_kernel<16>, grid, dim3(1024), 0, as_stream(stream), X, M, N, ldx, out, rpb);
+    if (vgb == 64) hipLaunchKernelGGL(colsum4_kernel<64>, grid, dim3(1024), 0, as_stream(stream), X, M, N, ldx, out, rpb, partial);
+    else if (vgb == 32) hipLaunchKernelGGL(colsum4_kernel<32>, grid, dim3(1024), 0, as_stream(stream), X, M, N, ldx, out, rpb, partial);
+    else hipLaunchKernelGGL(colsum4_kernel<16>, grid, dim3(1024), 0, as_stream(stream), X, M, N, ldx, out, rpb, partial);
+    if (partial)
+      hipLaunchKernelGGL(colsum_reduce_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, as_stream(stream), partial, chunks4, N, out,
+                         beta);
     return isic_launch_status();
   }
   // few column blocks x many rows (bias gradients over all the nodes of a batch): split the rows over blockIdx.y
@@ -331,11 +387,17 @@ int isic_tanh_bwd_f32(const float* dy, const float* t, float* dx, int64_t n, voi
 
 int isic_relu_dropout_fwd_f32(float* x, int64_t n, uint32_t drop_threshold, float drop_scale, uint64_t seed,
                               uint64_t stream_id, void* stream) {
+  return isic_relu_dropout_fwd_clk_f32(x, n, drop_threshold, drop_scale, seed, stream_id, nullptr, stream);
+}
+
+int isic_relu_dropout_fwd_clk_f32(float* x, int64_t n, uint32_t drop_threshold, float drop_scale, uint64_t seed,
+                                  uint64_t stream_id, const uint64_t* clock, void* stream) {
   ISIC_CHECK_ARG(n >= 0);
   if (n == 0) return ISIC_OK;
   ISIC_CHECK_ARG(x);
   hipLaunchKernelGGL(relu_dropout_fwd_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, as_stream(stream), x, n,
-                     drop_threshold, drop_scale, (unsigned long long)seed, (unsigned long long)stream_id);
+                     drop_threshold, drop_scale, (unsigned long long)seed, (unsigned long long)stream_id,
+                     (const unsigned long long*)clock);
   return isic_launch_status();
 }
 

@@ -19,7 +19,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ residual, float* __restrict__ y, float* __restrict__ mean_out,
     float* __restrict__ rstd_out, int M, int N, float eps, int relu, unsigned int thr, float scale,
-    unsigned long long seed, unsigned long long stream_id) {
+    unsigned long long seed, unsigned long long stream_id,
+    const unsigned long long* __restrict__ clock) {
+  if (clock) stream_id += clock[0] * 1024ULL;        // device step clock (captured graphs): stream = base + step * 1024
   const int lane = threadIdx.x & 63;
   const int row0 = blockIdx.x * 4 + (threadIdx.x >> 6);
   for (int row = row0; row < M; row += gridDim.x * 4) {
@@ -48,7 +50,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
     float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int N, int relu,
-    unsigned int thr, float scale, unsigned long long seed, unsigned long long stream_id) {
+    unsigned int thr, float scale, unsigned long long seed, unsigned long long stream_id,
+    const unsigned long long* __restrict__ clock) {
+  if (clock) stream_id += clock[0] * 1024ULL;        // device step clock (captured graphs): stream = base + step * 1024
   __shared__ float red[2][4][64 * JN];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float pg[JN], pb[JN];
@@ -115,7 +119,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ residual, float* __restrict__ y, float* __restrict__ mean_out,
     float* __restrict__ rstd_out, int M, float eps, int relu, unsigned int thr, float scale,
-    unsigned long long seed, unsigned long long stream_id) {
+    unsigned long long seed, unsigned long long stream_id,
+    const unsigned long long* __restrict__ clock) {
+  if (clock) stream_id += clock[0] * 1024ULL;        // device step clock (captured graphs): stream = base + step * 1024
   constexpr int RPW = 64 / LPR, N = 4 * LPR;
   const int lane = threadIdx.x & 63, sub = lane / LPR, col = (lane % LPR) * 4;
   const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + col), b4 = *reinterpret_cast<const f32x4*>(beta + col);
@@ -153,7 +159,9 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_vec_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
     float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int relu,
-    unsigned int thr, float scale, unsigned long long seed, unsigned long long stream_id) {
+    unsigned int thr, float scale, unsigned long long seed, unsigned long long stream_id,
+    const unsigned long long* __restrict__ clock) {
+  if (clock) stream_id += clock[0] * 1024ULL;        // device step clock (captured graphs): stream = base + step * 1024
   constexpr int RPW = 64 / LPR, N = 4 * LPR;
   __shared__ f32x4 red[2][1024];
   const int lane = threadIdx.x & 63, sub = lane / LPR, col = (lane % LPR) * 4;
@@ -290,10 +298,25 @@ __global__ void softmax_rows_bwd_kernel(const float* __restrict__ p, const float
 }
 
 // torch.optim.AdamW single-tensor order of operations (fp32), see header.
+// clock[0]: dropout step (stream id = base + clock[0] * 1024), clock[1]: optimizer steps taken.  One thread: the LAST
+// kernel of a captured step, so that every kernel of the step read the same values.
+__global__ void step_clock_advance_kernel(unsigned long long* __restrict__ clock, int dsteps, int osteps) {
+  clock[0] += (unsigned long long)dsteps;
+  clock[1] += (unsigned long long)osteps;
+}
+
 __global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                  float* __restrict__ v, int64_t n, float step_size, float beta1, float beta2,
                                  float eps, float decay_factor, float l2, float bc2_sqrt, float grad_scale,
-                                 unsigned short* __restrict__ p_bf16) {
+                                 unsigned short* __restrict__ p_bf16, const unsigned long long* __restrict__ clock,
+                                 float lr) {
+  if (clock) {
+    // device step clock (captured graphs): t = clock[1] + 1; step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t),
+    // formed in fp64 as the host does (optim.py)
+    const double t = (double)(clock[1] + 1ULL);
+    step_size = (float)((double)lr / (1.0 - pow((double)beta1, t)));
+    bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, t));
+  }
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const float w1 = 1.f - beta1, w2 = 1.f - beta2;
@@ -317,6 +340,13 @@ extern "C" {
 int isic_layernorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                        float* mean, float* rstd, int M, int N, float eps, int relu, uint32_t drop_threshold,
                        float drop_scale, uint64_t seed, uint64_t stream_id, void* stream) {
+  return isic_layernorm_fwd_clk(x, gamma, beta, residual, y, mean, rstd, M, N, eps, relu, drop_threshold, drop_scale, seed,
+                                stream_id, nullptr, stream);
+}
+
+int isic_layernorm_fwd_clk(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                           float* mean, float* rstd, int M, int N, float eps, int relu, uint32_t drop_threshold,
+                           float drop_scale, uint64_t seed, uint64_t stream_id, const uint64_t* clock, void* stream) {
   ISIC_CHECK_ARG(M >= 0 && N > 0);
   if (M == 0) return ISIC_OK;
   ISIC_CHECK_ARG(x && gamma && beta && y && mean && rstd);
@@ -329,7 +359,7 @@ int isic_layernorm_fwd(const float* x, const float* gamma, const float* beta, co
 #define LAUNCH_LNF(LPR)                                                                                              \
   hipLaunchKernelGGL(layernorm_fwd_vec_kernel<LPR>, dim3(gridv), dim3(256), 0, as_stream(stream), x, gamma, beta, residual, \
                      y, mean, rstd, M, eps, relu, drop_threshold, drop_scale, (unsigned long long)seed,              \
-                     (unsigned long long)stream_id)
+                     (unsigned long long)stream_id, (const unsigned long long*)clock)
     if (N == 64) LAUNCH_LNF(16); else if (N == 128) LAUNCH_LNF(32); else LAUNCH_LNF(64);
 #undef LAUNCH_LNF
     return isic_launch_status();
@@ -338,13 +368,21 @@ int isic_layernorm_fwd(const float* x, const float* gamma, const float* beta, co
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, gamma, beta, residual, y,
                      mean, rstd, M, N, eps, relu, drop_threshold, drop_scale, (unsigned long long)seed,
-                     (unsigned long long)stream_id);
+                     (unsigned long long)stream_id, (const unsigned long long*)clock);
   return isic_launch_status();
 }
 
 int isic_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
                        const float* rstd, float* dx, float* dgamma, float* dbeta, int M, int N, int relu,
                        uint32_t drop_threshold, float drop_scale, uint64_t seed, uint64_t stream_id, void* stream) {
+  return isic_layernorm_bwd_clk(dy, x, gamma, beta, mean, rstd, dx, dgamma, dbeta, M, N, relu, drop_threshold, drop_scale, seed,
+                                stream_id, nullptr, stream);
+}
+
+int isic_layernorm_bwd_clk(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
+                           const float* rstd, float* dx, float* dgamma, float* dbeta, int M, int N, int relu,
+                           uint32_t drop_threshold, float drop_scale, uint64_t seed, uint64_t stream_id,
+                           const uint64_t* clock, void* stream) {
   ISIC_CHECK_ARG(M >= 0 && N > 0);
   if (M == 0) return ISIC_OK;
   ISIC_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && dgamma && dbeta);
@@ -358,7 +396,7 @@ int isic_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
 #define LAUNCH_LNB(LPR)                                                                                             \
   hipLaunchKernelGGL(layernorm_bwd_vec_kernel<LPR>, dim3(gridv), dim3(1024), 0, as_stream(stream), dy, x, gamma, beta, mean, \
                      rstd, dx, dgamma, dbeta, M, relu, drop_threshold, drop_scale, (unsigned long long)seed,        \
-                     (unsigned long long)stream_id)
+                     (unsigned long long)stream_id, (const unsigned long long*)clock)
     if (N == 64) LAUNCH_LNB(16); else if (N == 128) LAUNCH_LNB(32); else LAUNCH_LNB(64);
 #undef LAUNCH_LNB
     return isic_launch_status();
@@ -369,7 +407,7 @@ int isic_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
 #define LAUNCH_LN(JN)                                                                                          \
   hipLaunchKernelGGL(layernorm_bwd_kernel<JN>, dim3(grid), dim3(256), 0, as_stream(stream), dy, x, gamma, beta, \
                      mean, rstd, dx, dgamma, dbeta, M, N, relu, drop_threshold, drop_scale,                     \
-                     (unsigned long long)seed, (unsigned long long)stream_id)
+                     (unsigned long long)seed, (unsigned long long)stream_id, (const unsigned long long*)clock)
   if (N <= 128) LAUNCH_LN(2);
   else if (N <= 256) LAUNCH_LN(4);
   else if (N <= 512) LAUNCH_LN(8);
@@ -434,7 +472,28 @@ int isic_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
   int64_t grid = (n + 255) / 256;
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(adam_step_kernel, dim3((int)grid), dim3(256), 0, as_stream(stream), p, g, m, v, n, step_size,
-                     beta1, beta2, eps, decay_factor, l2, bias_correction2_sqrt, grad_scale, p_bf16);
+                     beta1, beta2, eps, decay_factor, l2, bias_correction2_sqrt, grad_scale, p_bf16,
+                     (const unsigned long long*)nullptr, 0.f);
+  return isic_launch_status();
+}
+
+int isic_adam_step_clk(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                       float eps, float decay_factor, float l2, float grad_scale, uint16_t* p_bf16, const uint64_t* clock,
+                       void* stream) {
+  ISIC_CHECK_ARG(n >= 0 && clock);
+  if (n == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(p && g && m && v);
+  int64_t grid = (n + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(adam_step_kernel, dim3((int)grid), dim3(256), 0, as_stream(stream), p, g, m, v, n, 0.f, beta1, beta2, eps,
+                     decay_factor, l2, 1.f, grad_scale, p_bf16, (const unsigned long long*)clock, lr);
+  return isic_launch_status();
+}
+
+int isic_step_clock_advance(uint64_t* clock, int dropout_steps, int optimizer_steps, void* stream) {
+  ISIC_CHECK_ARG(clock && dropout_steps >= 0 && optimizer_steps >= 0);
+  hipLaunchKernelGGL(step_clock_advance_kernel, dim3(1), dim3(1), 0, as_stream(stream),
+                     reinterpret_cast<unsigned long long*>(clock), dropout_steps, optimizer_steps);
   return isic_launch_status();
 }
 

@@ -20,7 +20,12 @@ from .lib import IsicHipError, call
 
 LAYERS = ((64, 1), (128, 2), (256, 2), (512, 2))
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
-STAT_SLOTS = 32          # partial rows of the conv-epilogue BatchNorm statistics (spreads the fp64 atomics)
+# Partial rows of the conv-epilogue BatchNorm statistics.  The producing kernels are persistent (grid <= CU count = 256;
+# the stem launches up to 1024 blocks) and add a block's sums into row `block % slots`: with at least as many rows as
+# blocks every block owns its row, and `isic_bn_finalize` adds the rows in a fixed order -- the statistics, and with them
+# the whole forward, are bit-reproducible from run to run (round 3; 32 shared rows made them depend on arrival order).
+STAT_SLOTS = 256
+STEM_STAT_SLOTS = 1024
 _BF16 = torch.bfloat16
 
 
@@ -217,7 +222,7 @@ class ResNet18Encoder(nn.Module):
             p.grad = torch.zeros_like(p.data, memory_format=torch.preserve_format)
         return p.grad
 
-    _ARENA_DOUBLES = 2 * STAT_SLOTS * 4800 + 2 * 64 * STAT_SLOTS + 4096     # all conv / BN layers of ResNet-18, one pass
+    _ARENA_DOUBLES = 2 * STAT_SLOTS * 4800 + 2 * 64 * STEM_STAT_SLOTS + 8192     # all conv / BN layers of ResNet-18, one pass
 
     def _arena_reset(self, device):
         """Zero the statistics arena (one fill kernel instead of one torch.zeros per layer)."""
@@ -260,6 +265,14 @@ class ResNet18Encoder(nn.Module):
         for t in tensors:
             t.record_stream(side)     # the caching allocator must not hand the block out before the side work is done
 
+    def _workspace(self, nbytes, device):
+        """The weight-gradient workspace (source-offset table + split-K / per-block partials): one buffer, grown to the
+        largest request; the launches that use it are ordered on one stream (the side stream when it is on)."""
+        ws = self._wgrad_ws
+        if ws is None or ws.numel() < nbytes or ws.device != device:
+            ws = self._wgrad_ws = torch.empty(int(nbytes), device=device, dtype=torch.uint8)   # caching allocator: 512-B aligned
+        return ws
+
     def _conv_wgrad(self, x, dy, name):
         self._on_side(x.device, (x, dy), lambda: self._conv_wgrad_now(x, dy, name))
 
@@ -271,10 +284,7 @@ class ResNet18Encoder(nn.Module):
             raise IsicHipError(f"{name}.weight.grad must be channels_last ([O][Kh][Kw][I] memory)")
         N, H, W, C = x.shape
         _, Ho, Wo, Co = dy.shape
-        nbytes = call("isic_conv2d_wgrad_workspace_bytes", N, C, Ho, Wo, Co, sp.k, sp.k)
-        ws = self._wgrad_ws
-        if ws is None or ws.numel() < nbytes or ws.device != x.device:
-            ws = self._wgrad_ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)   # caching allocator: 512-B aligned
+        ws = self._workspace(call("isic_conv2d_wgrad_workspace_bytes", N, C, Ho, Wo, Co, sp.k, sp.k), x.device)
         call("isic_conv2d_wgrad_bf16", x, dy, g, N, H, W, C, Ho, Wo, Co, sp.k, sp.k, sp.stride, sp.pad, ws, ws.numel())
 
     def _bn_fwd(self, c, name, relu, residual=None, acc=None):
@@ -301,7 +311,7 @@ class ResNet18Encoder(nn.Module):
         shift = torch.empty(C, device=dev, dtype=torch.float32)
         mean = rstd = None
         if self.training:
-            slots = STAT_SLOTS
+            slots = int(acc.shape[1]) if acc is not None else 1
             if acc is None:
                 slots = 1
                 acc = self._zeros64((2, 1, C), dev)
@@ -431,8 +441,8 @@ class ResNet18Encoder(nn.Module):
         c = _empty((N, Ho, Wo, 64), x0)
         acc0 = None
         if self.training:      # batch statistics of bn1 fused into the stem convolution's epilogue
-            acc0 = self._zeros64((2, STAT_SLOTS, 64), x0.device)
-            call("isic_conv_stem_fwd_stats_bf16", x0, ws, c, N, H, W, Ho, Wo, acc0[0], acc0[1], STAT_SLOTS)
+            acc0 = self._zeros64((2, STEM_STAT_SLOTS, 64), x0.device)
+            call("isic_conv_stem_fwd_stats_bf16", x0, ws, c, N, H, W, Ho, Wo, acc0[0], acc0[1], STEM_STAT_SLOTS)
         else:
             call("isic_conv_stem_fwd_bf16", x0, ws, c, N, H, W, Ho, Wo)
         # bn1 + relu + maxpool in one pass over the stem activation (the largest tensor of the network): the
@@ -518,9 +528,10 @@ class ResNet18Encoder(nn.Module):
         x0 = tape["x0"]
         p = self._get("conv1.weight")
         gw, gg, gb = self._grad_buffer(p), self._grad_buffer(gamma), self._grad_buffer(beta)
+        ws = self._workspace(call("isic_conv_stem_wgrad_workspace_bytes"), c.device)
         self._on_side(c.device, (x0, c, g, am, acc),
                       lambda: call("isic_conv_stem_wgrad_bn_pooled_bf16", x0, c, am, g, mean, rstd, gamma.data, scale, shift,
-                                   acc[0], acc[1], gw, gg, gb, N, x0.shape[1], x0.shape[2], Ho, Wo, Hp, Wp))
+                                   acc[0], acc[1], gw, gg, gb, N, x0.shape[1], x0.shape[2], Ho, Wo, Hp, Wp, ws, ws.numel()))
         self._fire(["conv1.weight", "bn1.weight", "bn1.bias"])
         if self._side is not None:
             torch.cuda.current_stream(c.device).wait_stream(self._side)    # gradients complete for whoever comes next

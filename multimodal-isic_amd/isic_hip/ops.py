@@ -19,9 +19,11 @@ ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 class DropoutSpec:
     """Counter-based dropout site: keep iff philox_word(i; seed, stream) >= threshold."""
 
-    __slots__ = ("p", "threshold", "scale", "seed", "stream")
+    __slots__ = ("p", "threshold", "scale", "seed", "stream", "clock")
 
-    def __init__(self, p=0.0, seed=0, stream=0):
+    def __init__(self, p=0.0, seed=0, stream=0, clock=None):
+        """``clock``: device step clock (uint64[2] tensor, ``graphs.StepClock``): the kernels then add clock[0] * 1024 to
+        ``stream`` themselves, so that a captured (hipGraph) train step draws new words on every replay."""
         self.p = float(p)
         if not 0.0 <= self.p < 1.0:
             raise ValueError(f"dropout probability has to be in [0, 1), got {p}")
@@ -31,6 +33,7 @@ class DropoutSpec:
                                                                    - torch.tensor(self.p, dtype=torch.float32)))
         self.seed = int(seed)
         self.stream = int(stream)
+        self.clock = clock
 
     @property
     def active(self):
@@ -68,15 +71,34 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, out=None, 
     for t in (a, b, out):      # row-major with a leading dimension: strided row views are fine, the inner stride is not
         if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1) or not t.is_cuda or t.dtype != torch.float32:
             raise IsicHipError("gemm operands must be 2-D fp32 device tensors with unit inner stride")
-    call("isic_gemm_f32", int(trans_a), int(trans_b), M, N, K, a.data_ptr(), max(a.stride(0), a.shape[1]), b.data_ptr(),
-         max(b.stride(0), b.shape[1]), out.data_ptr(), max(out.stride(0), out.shape[1]), bias, act, float(beta))
+    ws = _workspace(call("isic_gemm_f32_workspace_bytes", int(trans_a), int(trans_b), M, N, K), a.device)
+    call("isic_gemm_f32_ws", int(trans_a), int(trans_b), M, N, K, a.data_ptr(), max(a.stride(0), a.shape[1]), b.data_ptr(),
+         max(b.stride(0), b.shape[1]), out.data_ptr(), max(out.stride(0), out.shape[1]), bias, act, float(beta),
+         ws, ws.numel() if ws is not None else 0)
     return out
+
+
+_WS = {}
+
+
+def _workspace(nbytes, device):
+    """Split-K / row-chunk partials of the deterministic reductions: one buffer per device, grown to the largest request
+    (the launches that use it are ordered on the stream; a fixed address keeps a captured graph valid)."""
+    if not nbytes:
+        return None
+    key = (device.type, device.index)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _WS[key] = torch.empty(max(int(nbytes), 64 << 20), device=device, dtype=torch.uint8)
+    return ws
 
 
 def colsum(x, out=None, beta=0.0):
     if out is None:
         out = torch.empty((x.shape[1],), device=x.device, dtype=torch.float32)
-    call("isic_colsum_f32", x, x.shape[0], x.shape[1], x.stride(0), out, float(beta))
+    ws = _workspace(call("isic_colsum_f32_workspace_bytes", x.shape[0], x.shape[1]), x.device)
+    call("isic_colsum_f32_ws", x, x.shape[0], x.shape[1], x.stride(0), out, float(beta), ws,
+         ws.numel() if ws is not None else 0)
     return out
 
 
@@ -95,7 +117,7 @@ class LinearFn(torch.autograd.Function):
             raise ValueError("fused dropout is defined after ReLU only")
         if drop.active:
             y = gemm(x2, w, trans_b=True, bias=b, act=ACT_NONE)
-            call("isic_relu_dropout_fwd_f32", y, y.numel(), drop.threshold, drop.scale, drop.seed, drop.stream)
+            call("isic_relu_dropout_fwd_clk_f32", y, y.numel(), drop.threshold, drop.scale, drop.seed, drop.stream, drop.clock)
         else:
             y = gemm(x2, w, trans_b=True, bias=b, act=act)
         ctx.act, ctx.drop_scale, ctx.has_bias = act, (drop.scale if drop.active else 1.0), bias is not None
@@ -136,7 +158,7 @@ class ReluDropoutFn(torch.autograd.Function):
         _chk(x)
         drop = drop or NO_DROP
         y = _f32c(x).clone()
-        call("isic_relu_dropout_fwd_f32", y, y.numel(), drop.threshold, drop.scale, drop.seed, drop.stream)
+        call("isic_relu_dropout_fwd_clk_f32", y, y.numel(), drop.threshold, drop.scale, drop.seed, drop.stream, drop.clock)
         ctx.scale = drop.scale if drop.active else 1.0
         ctx.save_for_backward(y)
         return y
@@ -246,8 +268,8 @@ class LayerNormFn(torch.autograd.Function):
         y = torch.empty_like(x2)
         mean = torch.empty((M,), device=x2.device, dtype=torch.float32)
         rstd = torch.empty((M,), device=x2.device, dtype=torch.float32)
-        call("isic_layernorm_fwd", x2, g, b, res, y, mean, rstd, M, N, float(eps), int(relu), drop.threshold,
-             drop.scale, drop.seed, drop.stream)
+        call("isic_layernorm_fwd_clk", x2, g, b, res, y, mean, rstd, M, N, float(eps), int(relu), drop.threshold,
+             drop.scale, drop.seed, drop.stream, drop.clock)
         ctx.cfg = (M, N, int(relu), drop)
         ctx.has_res = residual is not None
         ctx.xshape = x.shape
@@ -262,8 +284,8 @@ class LayerNormFn(torch.autograd.Function):
         dx = torch.empty_like(x2)
         dg = torch.zeros((N,), device=x2.device, dtype=torch.float32)
         db = torch.zeros((N,), device=x2.device, dtype=torch.float32)
-        call("isic_layernorm_bwd", dy2, x2, g, b, mean, rstd, dx, dg, db, M, N, relu, drop.threshold, drop.scale,
-             drop.seed, drop.stream)
+        call("isic_layernorm_bwd_clk", dy2, x2, g, b, mean, rstd, dx, dg, db, M, N, relu, drop.threshold, drop.scale,
+             drop.seed, drop.stream, drop.clock)
         return dx.reshape(ctx.xshape), dg, db, (dy if ctx.has_res else None), None, None, None
 
 

@@ -58,6 +58,7 @@ class _FlatAdamBase:
         self.exp_avg = torch.zeros_like(self.flat.data)
         self.exp_avg_sq = torch.zeros_like(self.flat.data)
         self.t = 0
+        self.device_clock = None       # graphs.StepClock.tensor: t = clock[1] + 1 is then read on the device (captured steps)
         self.param_groups = [{"params": self.flat.params, "lr": self.lr, "betas": self.betas, "eps": self.eps,
                               "weight_decay": self.weight_decay}]
 
@@ -65,9 +66,14 @@ class _FlatAdamBase:
         self.flat.zero_grad()
 
     def step(self, grad_scale=1.0):
-        self.t += 1
         g = self.param_groups[0]
         lr, (b1, b2), wd = float(g["lr"]), g["betas"], float(g["weight_decay"])
+        if self.device_clock is not None:
+            call("isic_adam_step_clk", self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.flat.numel, lr, b1,
+                 b2, float(g["eps"]), (1.0 - lr * wd) if self.decoupled else 1.0, 0.0 if self.decoupled else wd,
+                 float(grad_scale), None, self.device_clock)
+            return
+        self.t += 1
         bc1 = 1.0 - b1 ** self.t
         bc2_sqrt = math.sqrt(1.0 - b2 ** self.t)
         call("isic_adam_step", self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.flat.numel,

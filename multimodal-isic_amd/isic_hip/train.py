@@ -58,10 +58,17 @@ class BagStore:
         lens = {int(b.shape[0]) for b in bags}
         self.uniform = len(lens) == 1
         self.lengths = [int(b.shape[0]) for b in bags]
-        if self.uniform:
+
+        def dev(b):            # numpy latents (`01_train_mil_teacher.py:51-67`) or tensors already resident in HBM
+            if isinstance(b, torch.Tensor):
+                return b.to(device=device, dtype=torch.float32)
+            return torch.as_tensor(np.asarray(b, dtype=np.float32)).to(device)
+        if self.uniform and not any(isinstance(b, torch.Tensor) for b in bags):
             self.data = torch.as_tensor(np.stack([np.asarray(b, dtype=np.float32) for b in bags])).to(device)
+        elif self.uniform:
+            self.data = torch.stack([dev(b) for b in bags])
         else:
-            self.data = [torch.as_tensor(np.asarray(b, dtype=np.float32)).to(device) for b in bags]
+            self.data = [dev(b) for b in bags]
 
     def batch(self, idx):
         if self.uniform:

@@ -110,6 +110,18 @@ class DeviceTeacherOutputs:
 
 
 @torch.no_grad()
+def with_radiomic_node_features(x, radiomics):
+    """BASELINE.json configs[3]: "k-NN graphs on patch embeddings + radiomic node feats".  The reference's graph records
+    carry the patch embeddings only (`05_train_gnns.py:248-270`: ``x[196, 768]``) and its radiomics are zero-stubbed
+    (`dataset.py:42`), so there is no reference layout to follow: the lesion-level radiomic vector is appended to EVERY
+    node of its graph (``x[G, N, D]``, ``radiomics[G, R]`` -> ``[G, N, D + R]``); the k-NN edges stay those of the patch
+    embeddings.  Stays on the device."""
+    if x.dim() != 3 or radiomics.dim() != 2 or radiomics.shape[0] != x.shape[0]:
+        raise ValueError(f"expected x[G,N,D] and radiomics[G,R], got {tuple(x.shape)} and {tuple(radiomics.shape)}")
+    G, N, _ = x.shape
+    return torch.cat([x, radiomics.to(x.dtype).unsqueeze(1).expand(G, N, radiomics.shape[1])], dim=2).contiguous()
+
+
 def collect_teacher_outputs_device(model, bags, labels, image_ids, device, chunk=256, kmax=16):
     """`_collect_teacher_outputs` (`01_train_mil_teacher.py:69-87`) with every output left on the device.
     ``bags``: list of equal-sized [N, D] arrays or one [G, N, D] tensor."""

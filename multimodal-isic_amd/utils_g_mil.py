@@ -32,6 +32,10 @@ class _DropoutClock:
         self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
         self.step = 0
         self.rank = rank       # None: torch.distributed rank at use time (0 when not initialised)
+        # device step clock (isic_hip.graphs.StepClock.tensor): the step then lives in HBM and the kernels add it to the
+        # stream id themselves -- what lets a whole train step be captured into a hipGraph and replayed; ``step`` is
+        # ignored while it is set
+        self.device_clock = None
 
     def _rank(self):
         if self.rank is not None:
@@ -42,6 +46,8 @@ class _DropoutClock:
     def spec(self, p, site, training):
         if not training or p <= 0.0:
             return None
+        if self.device_clock is not None:
+            return ops.DropoutSpec(p, self.seed, (self._rank() << 44) + site, clock=self.device_clock)
         return ops.DropoutSpec(p, self.seed, (self._rank() << 44) + self.step * 1024 + site)
 
 

@@ -193,6 +193,7 @@ def backward(force, side):
         orig(lo)
     sync.mark_ready = spy
     opt.zero_grad(); sync.reset()
+    net.set_dropout_state(seed=5, step=0)               # the projection / fusion MLPs drop out in train mode: same words every time
     net.loss(net(img, rad), y).backward()
     launched = sync.finish()
     torch.cuda.synchronize()
@@ -204,7 +205,12 @@ for side in (False, True):
     key = "side" if side else "main"
     # world 1: the all-reduce is an identity, so what it leaves behind must be what backward wrote ...
     ok_snap = all(bool(torch.equal(s, got[lo:])) for lo, s in snaps)
-    # ... and equal (up to the atomics' summation order) to a backward without any collective
+    # ... and equal to a backward without any collective.  Only the ENCODER's gradients are compared bit for bit (the
+    # encoder step is bit-reproducible since round 3; the few head gradients go through split-K fp32 atomics)
+    enc_lo = min(o for p_, o in zip(flat.params, flat.offsets) if any(p_ is q for q in net.encoder.parameters()))
+    enc_hi = max(o + p_.numel() for p_, o in zip(flat.params, flat.offsets) if any(p_ is q for q in net.encoder.parameters()))
+    out.setdefault("encoder_equal", True)
+    out["encoder_equal"] = out["encoder_equal"] and bool(torch.equal(got[enc_lo:enc_hi], ref[enc_lo:enc_hi]))
     rel = float((got - ref).norm() / ref.norm())
     cover = sorted(launched)
     tiled = cover[0][0] == 0 and cover[-1][1] == flat.numel and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
@@ -250,5 +256,6 @@ def test_rccl_collectives_from_a_real_backward_world_size_1(tmp_path):
     for key in ("main", "side"):
         assert res[key]["snapshots_equal_final"], res
         assert res[key]["tiled"] and res[key]["collectives"] >= 3, res
-        assert res[key]["rel_vs_no_collective"] < 0.05, res      # bf16 chaos + atomics order between two backwards; a clobbered bucket reads ~1
+        assert res[key]["rel_vs_no_collective"] < 1e-4, res      # head gradients: fp32 atomics order only; a clobbered bucket reads ~1
+    assert res["encoder_equal"], res
     assert res["next_step_finite"] and res["plain_allreduce_identity"], res

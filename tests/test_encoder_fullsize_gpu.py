@@ -219,3 +219,154 @@ def test_configs1_full_size_forward_backward(images):
             assert torch.equal(a, b), f"{k}: the all-taps weight gradient must be deterministic"
         else:
             assert _rel(a, b) < 1e-4, k               # fp32 / fp64 atomics: last-bit differences only
+
+
+@pytest.mark.parametrize("images", [96, 2048])
+def test_training_step_is_bit_reproducible(images):
+    """the SAME step run twice -- forward from the images, backward from the same feature gradient --
+    must give bit-identical features, BatchNorm statistics and EVERY encoder parameter gradient, at the configs[1] size
+    (2048 images of 224x224: every persistent kernel at its full grid) and at a small size (few tiles per block, the
+    stem below its block cap).  What made two runs differ before round 3: LDS / fp64 atomics in arrival order inside the
+    fused BatchNorm statistics of conv_halo / conv3x3_c64p / conv_pgemm / the stem, and fp32 atomics in 7 of the 20
+    weight gradients; 17 bf16 layers amplified those last-bit differences to per cent in the gradients."""
+    from isic_hip.encoder import ResNet18Encoder
+    torch.manual_seed(5)
+    enc = ResNet18Encoder().to(DEV)
+    enc.train()
+    gen = torch.Generator(device=DEV).manual_seed(13)
+    S = 224 if images >= 1024 else 96
+    x = torch.randn(images, 3, S, S, device=DEV, generator=gen).to(BF)
+    dfeat = torch.randn(images, 512, device=DEV, generator=gen) / images
+
+    def run():
+        for p in enc.parameters():
+            p.grad = None
+        feat, tape = enc.run_forward(x, save=True)
+        stats = [tape["stem"][1][0].clone(), tape["stem"][1][1].clone()]
+        for saved in tape["blocks"]:
+            for st in (saved[3], saved[6], saved[8]):
+                if st is not None:
+                    stats += [st[0].clone(), st[1].clone()]
+        enc.run_backward(tape, dfeat)
+        torch.cuda.synchronize()
+        return feat.clone(), stats, {k: p.grad.detach().clone() for k, p in enc.named_parameters()}
+
+    f1, s1, g1 = run()
+    f2, s2, g2 = run()
+    assert torch.equal(f1, f2), "features differ between two identical forwards"
+    assert all(torch.equal(a, b) for a, b in zip(s1, s2)), "BatchNorm batch statistics differ between two identical forwards"
+    diff = [k for k in g1 if not torch.equal(g1[k], g2[k])]
+    assert not diff, f"parameter gradients differ between two identical steps: {diff}"
+    assert all(bool(torch.isfinite(v).all()) and float(v.abs().max()) > 0 for v in g1.values())
+
+
+def _ref_block(x, P, stride, ds):
+    """torch-CPU fp32 restatement of one BasicBlock with the HIP path's bf16 rounding points (the dataflow of
+    test_block_backward_teacher_forced, as a function): returns (out, backward) with backward(gout) -> (dx, grads)."""
+    from torch.nn.grad import conv2d_input, conv2d_weight
+    v = lambda t: t.view(1, -1, 1, 1)
+    w1, w2 = P["conv1.weight"], P["conv2.weight"]
+    c1 = _rb(F.conv2d(x, w1, None, stride, 1))
+    m1, r1, sc1, sh1 = _bn_stats(c1, P["bn1.weight"], P["bn1.bias"])
+    pre1 = c1 * v(sc1) + v(sh1)
+    a1 = _rb(torch.relu(pre1))
+    c2 = _rb(F.conv2d(a1, w2, None, 1, 1))
+    m2, r2, sc2, sh2 = _bn_stats(c2, P["bn2.weight"], P["bn2.bias"])
+    idn = x
+    if ds:
+        wd = P["downsample.0.weight"]
+        cd = _rb(F.conv2d(x, wd, None, stride, 0))
+        md, rd, scd, shd = _bn_stats(cd, P["downsample.1.weight"], P["downsample.1.bias"])
+        idn = _rb(cd * v(scd) + v(shd))
+    out = _rb(torch.relu(c2 * v(sc2) + v(sh2) + idn))
+
+    def backward(gout):
+        G = {}
+        dz2 = gout * (out > 0).float()
+        dc2, G["bn2.weight"], G["bn2.bias"] = _bn_bwd(dz2, c2, m2, r2, P["bn2.weight"])
+        G["conv2.weight"] = conv2d_weight(a1, w2.shape, dc2, 1, 1)
+        da1 = _rb(conv2d_input(a1.shape, w2, dc2, 1, 1))
+        dz1 = da1 * (pre1 > 0).float()
+        dc1, G["bn1.weight"], G["bn1.bias"] = _bn_bwd(dz1, c1, m1, r1, P["bn1.weight"])
+        G["conv1.weight"] = conv2d_weight(x, w1.shape, dc1, stride, 1)
+        dx_main = conv2d_input(x.shape, w1, dc1, stride, 1)
+        if ds:
+            dcd, G["downsample.1.weight"], G["downsample.1.bias"] = _bn_bwd(dz2, cd, md, rd, P["downsample.1.weight"])
+            G["downsample.0.weight"] = conv2d_weight(x, wd.shape, dcd, stride, 0)
+            dx = _rb(dx_main + _rb(conv2d_input(x.shape, wd, dcd, stride, 0)))
+        else:
+            dx = _rb(dx_main + dz2)
+        return dx, G
+    return out, backward
+
+
+def test_three_block_chain_backward():
+    """the COMPOSITION of blocks -- layer1.1 -> layer2.0 (stride 2 + 1x1 downsample) -> layer2.1 run as
+    a chain, forward and backward, on the HIP path against the same chain of torch-CPU fp32 blocks that round to bf16 at
+    the same points.  Unlike the per-block test nothing is re-injected between blocks: block i's dx is block i-1's
+    upstream gradient, the residual-gradient joins and the 64 -> 128 channel / stride-2 hand-over are inside the
+    comparison.  <= 3 % (norm-wise) for the input gradient of the chain and every parameter gradient of the three blocks,
+    <= 1 % for the chain's output."""
+    from isic_hip.encoder import ResNet18Encoder
+    chain = [("layer1.1", 64, 64, 1), ("layer2.0", 64, 128, 2), ("layer2.1", 128, 128, 1)]
+    N, H = 12, 24
+    torch.manual_seed(77)
+    enc = ResNet18Encoder().to(DEV)
+    enc.train()
+    g = torch.Generator().manual_seed(17)
+    Ps, names_all = [], []
+    with torch.no_grad():
+        for pre, cin, planes, stride in chain:
+            ds = stride != 1 or cin != planes
+            names = [f"{pre}.conv1.weight", f"{pre}.bn1.weight", f"{pre}.bn1.bias", f"{pre}.conv2.weight", f"{pre}.bn2.weight",
+                     f"{pre}.bn2.bias"] + ([f"{pre}.downsample.0.weight", f"{pre}.downsample.1.weight",
+                                            f"{pre}.downsample.1.bias"] if ds else [])
+            P = {}
+            for k in names:
+                p = enc._get(k)
+                if p.dim() == 4:
+                    val = _rb(torch.randn(p.shape, generator=g) * float(np.sqrt(2.0 / (p.shape[0] * p.shape[2] * p.shape[3]))))
+                elif k.endswith("weight"):
+                    val = 1.0 + 0.2 * torch.randn(p.shape, generator=g)
+                else:
+                    val = 0.1 * torch.randn(p.shape, generator=g)
+                p.copy_(val.to(DEV).contiguous(memory_format=torch.channels_last) if p.dim() == 4 else val.to(DEV))
+                P[k[len(pre) + 1:]] = val.clone()
+            Ps.append(P)
+            names_all.append(names)
+    x = _rb(torch.relu(torch.randn(N, 64, H, H, generator=g)))
+    # ---- reference chain
+    t, bwds = x, []
+    for (pre, cin, planes, stride), P in zip(chain, Ps):
+        t, b = _ref_block(t, P, stride, stride != 1 or cin != planes)
+        bwds.append(b)
+    out_ref = t
+    gout = _rb(1.0 + 0.5 * torch.randn(out_ref.shape, generator=g))
+    gr, Gs = gout, []
+    for b in reversed(bwds):
+        gr, G = b(gr)
+        Gs.append(G)
+    Gs.reverse()
+    dx_ref = gr
+    # ---- HIP chain
+    enc.prepare_weights()
+    enc._arena_reset(torch.device(DEV))
+    h, saved = x.permute(0, 2, 3, 1).contiguous().to(DEV, BF), []
+    for pre, cin, planes, stride in chain:
+        h, s = enc.block_forward(h, pre, stride != 1 or cin != planes)
+        saved.append(s)
+    assert _rel(h.float().cpu().permute(0, 3, 1, 2), out_ref) < 0.01
+    for names in names_all:
+        for k in names:
+            enc._get(k).grad = None
+    enc._arena_reset(torch.device(DEV))
+    gd = gout.permute(0, 2, 3, 1).contiguous().to(DEV, BF)
+    for (pre, cin, planes, stride), s in zip(reversed(chain), reversed(saved)):
+        gd, _ = enc.block_backward(gd, pre, stride != 1 or cin != planes, s)
+    torch.cuda.synchronize()
+    errs = {"dx": _rel(gd.float().cpu().permute(0, 3, 1, 2), dx_ref)}
+    for (pre, *_), names, G in zip(chain, names_all, Gs):
+        for k in names:
+            errs[k] = _rel(enc._get(k).grad.cpu(), G[k[len(pre) + 1:]])
+    bad = {k: round(e, 4) for k, e in errs.items() if e > 0.03}
+    assert not bad, f"3-block chain: relative gradient errors above 3 %: {bad} (all: { {k: round(e, 4) for k, e in errs.items()} })"

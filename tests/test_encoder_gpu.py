@@ -525,13 +525,15 @@ def test_stem_wgrad_from_pooled_gradient(shape):
     call("isic_bn_bwd_apply_pooled_bf16", am, gp, y0, mean, rstd, gamma, acc[0], acc[1], N, Ho, Wo, C, Hp, Wp, scale, shift,
          dy, dg_ref, db_ref)
     dw_ref = torch.zeros(64, 3, 7, 7, device=DEV).contiguous(memory_format=torch.channels_last)
-    call("isic_conv_stem_wgrad_bf16", x4, dy, dw_ref, N, H, W, Ho, Wo)
+    wsp = torch.empty(call("isic_conv_stem_wgrad_workspace_bytes"), device=DEV, dtype=torch.uint8)
+    call("isic_conv_stem_wgrad_bf16", x4, dy, dw_ref, N, H, W, Ho, Wo, wsp, wsp.numel())
     dw = torch.zeros_like(dw_ref)
     dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     call("isic_conv_stem_wgrad_bn_pooled_bf16", x4, y0, am, gp, mean, rstd, gamma, scale, shift, acc[0], acc[1], dw, dg, db,
-         N, H, W, Ho, Wo, Hp, Wp)
+         N, H, W, Ho, Wo, Hp, Wp, wsp, wsp.numel())
     assert torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
-    # identical bf16 operands and tiles; only the order of the fp32 atomics differs
+    # identical bf16 operands, tiles and (since round 3) summation order: both kernels leave per-block partials that are
+    # added in block order
     assert_close(dw.cpu(), dw_ref.cpu(), rtol=1e-4, atol=1e-4 * float(dw_ref.abs().max().cpu()), what="fused stem wgrad")
 
 
@@ -562,7 +564,8 @@ def test_stem_forward_and_wgrad(shape):
     assert_close(st[0].sum(0), o.sum(0), rtol=1e-5, atol=1e-4, what="stem fused sum")
     assert_close(st[1].sum(0), (o * o).sum(0), rtol=1e-5, atol=1e-4, what="stem fused sumsq")
     dw = torch.zeros(64, 3, 7, 7, device=DEV).contiguous(memory_format=torch.channels_last)
-    call("isic_conv_stem_wgrad_bf16", x4, nhwc(dy), dw, N, H, W, Ho, Wo)
+    wsp = torch.empty(call("isic_conv_stem_wgrad_workspace_bytes"), device=DEV, dtype=torch.uint8)
+    call("isic_conv_stem_wgrad_bf16", x4, nhwc(dy), dw, N, H, W, Ho, Wo, wsp, wsp.numel())
     assert_close(dw.cpu(), w.grad, rtol=2e-4, atol=1e-5, what=f"stem wgrad {shape}")
 
 

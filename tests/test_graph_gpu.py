@@ -245,7 +245,7 @@ def test_gat_attention_dropout_matches_oracle():
 
 
 @pytest.mark.parametrize("gtype,F_,heads", [("gatv2", 64, 4), ("gatv2", 128, 4), ("gatv2", 256, 4), ("gatv2", 32, 4), ("gatv2", 96, 2),
-                                            ("gatv2", 328, 4),      # 4 x 6 register slots > 16: the per-row atomic path of d att
+                                            ("gatv2", 168, 6),      # 6 heads x 3 register slots > 16: the per-row atomic path of d att
                                             ("transformer", 32, 4), ("transformer", 48, 2),
                                             ("fagcn", 64, 4), ("fagcn", 96, 4)])
 def test_graphmil_edge_attention_models_vs_oracle(gtype, F_, heads):

@@ -145,3 +145,56 @@ def test_gemm_split_k_and_chunked_colsum(shape, beta):
     o = o0.clone().to(DEV)
     ops.colsum(x.to(DEV), out=o, beta=beta)
     assert_close(o.cpu(), x.double().sum(0) + beta * o0.double(), rtol=2e-6, atol=1e-4, what=f"colsum {shape} beta={beta}")
+
+
+# (M, N, K, trans_a, trans_b, bias, act): the graph path's products at a batch of 256 graphs (05_train_gnns.py:168-199) and
+# edge cases of the persistent LDS-DMA kernel (gemm_f32p.hip): every operand layout, the swapped (C^T) roles, split-K,
+# ragged M / N / K (multiples of 4 that are not multiples of the 256 x 128 x 32 tile), leading dimensions > width
+PGEMM_CASES = [
+    (50176, 128, 768, False, True, True, 1),       # input_proj forward: x W^T + b, ReLU
+    (50176, 128, 128, False, True, True, 2),       # 128-wide layer forward, tanh (attention heads)
+    (50176, 768, 128, False, False, False, 0),     # dX = dY W
+    (128, 768, 50176, True, False, False, 0),      # dW = dY^T X: swapped roles, split-K over 50 176 nodes
+    (512, 128, 50176, True, False, False, 0),      # dW of the concatenated attention heads: split-K, no swap
+    (128, 128, 50176, True, False, False, 0),      # dW of a GCN layer
+    (30000, 132, 100, False, True, True, 0),       # ragged everything, k contiguous x k contiguous
+    (3004, 260, 2052, False, False, False, 0),     # ragged, k contiguous x k strided
+    (1100, 520, 4100, True, True, True, 0),        # k strided x k contiguous with a bias (un-swapped)
+    (260, 1028, 8200, True, False, False, 0),      # k strided x k strided, split-K, ragged
+]
+
+
+@pytest.mark.parametrize("case", PGEMM_CASES, ids=[f"{c[0]}x{c[1]}x{c[2]}{'T' if c[3] else 'N'}{'T' if c[4] else 'N'}" for c in PGEMM_CASES])
+@pytest.mark.parametrize("beta", [0.0, 1.0])
+def test_persistent_fp32_gemm(case, beta):
+    """`isic_gemm_f32_ws` on the shapes that take the persistent 256 x 128 x 32 kernel: against an fp64 product (exact-fp32
+    MFMA: only the summation order differs, 2e-6 of the output scale per 1000 k), bit-identical between two runs (split-K
+    partials are added in split order: no atomics), and with padded leading dimensions."""
+    from isic_hip import ops
+    from isic_hip.lib import call
+    M, N, K, ta, tb, has_bias, act = case
+    assert call("isic_gemm_f32_workspace_bytes", int(ta), int(tb), M, N, K) >= 0
+    g = torch.Generator().manual_seed(M + N + K)
+    pad_a, pad_b, pad_c = 8, 4, 12                  # leading dimensions wider than the matrices (strided row views)
+    a_full = torch.randn((K, M + pad_a) if ta else (M, K + pad_a), generator=g).to(DEV)
+    b_full = torch.randn((N, K + pad_b) if tb else (K, N + pad_b), generator=g).to(DEV)
+    a = a_full[:, :M] if ta else a_full[:, :K]
+    b = b_full[:, :K] if tb else b_full[:, :N]
+    bias = torch.randn(N, generator=g).to(DEV) if has_bias else None
+    c0 = torch.randn(M, N + pad_c, generator=g).to(DEV)
+
+    def run():
+        c = c0.clone()
+        ops.gemm(a, b, trans_a=ta, trans_b=tb, bias=bias, act=act, out=c[:, :N], beta=beta)
+        torch.cuda.synchronize()
+        return c
+    c1, c2 = run(), run()
+    assert torch.equal(c1, c2), "two runs of the same product differ: the split-K reduction must be order-fixed"
+    assert torch.equal(c1[:, N:], c0[:, N:]), "wrote outside the output columns"
+    ref = (a.t() if ta else a).double() @ (b.t() if tb else b).double()
+    if has_bias:
+        ref = ref + bias.double()
+    ref = torch.relu(ref) if act == 1 else torch.tanh(ref) if act == 2 else ref
+    ref = ref + beta * c0[:, :N].double()
+    tol = 2e-6 * max(1.0, K / 1000.0) * (1.0 if act != 2 else 4.0)
+    assert_close(c1[:, :N], ref, rtol=tol, atol=tol * float(K) ** 0.5, what=f"persistent gemm {case} beta={beta}")

@@ -155,7 +155,10 @@ def test_encoder_is_deterministic_and_batch_invariant():
 def test_configs4_pipeline_vit_tokens_to_teacher_to_heterophily_aware_gnn():
     """BASELINE.json configs[4] end to end at toy scale: images -> frozen ViT-S/16 tokens (fp16 MFMA) -> attention-MIL
     teacher trained on the 196-token bags -> teacher outputs, dominant classes and k-NN graphs kept on the device
-    (pipeline.py) -> edge heterophily -> a heterophily-aware GNN (GCNII) trained on those graphs."""
+    (pipeline.py) -> edge heterophily -> a heterophily-aware GNN (GCNII) trained on those graphs.  The tokens never leave
+    HBM, and the hand-over is checked against the CPU path: the teacher outputs the pipeline keeps on
+    the device == `oracle.mil.teacher_forward` with the trained parameters on the same tokens, its k-NN lists == the
+    neighbours `oracle.graphs.knn_edge_index` (`03_build_graphs.py:37-54`) builds from them."""
     import numpy as np
     import measure_heterophily as mh
     import pipeline
@@ -174,7 +177,7 @@ def test_configs4_pipeline_vit_tokens_to_teacher_to_heterophily_aware_gnn():
         images[i, :, (y // 2) * 112:(y // 2) * 112 + 112, (y % 2) * 112:(y % 2) * 112 + 112] += 1.5
     tokens = enc.run_tokens(images.to(dev))                            # [G, 196, 384] fp32 on the device
     assert tokens.is_cuda and tokens.shape == (G, 196, 384) and bool(torch.isfinite(tokens).all())
-    bags = [t for t in tokens.cpu().numpy()]
+    bags = [tokens[i] for i in range(G)]                               # views of the resident token tensor: no host round trip
     tr_i, va_i = np.arange(0, 20), np.arange(20, G)
     teacher = AttentionMIL_teacher(384, 64, 32, dropout=0.1, num_classes=C).to(dev)
     res = T.train_teacher_fold(teacher, [bags[i] for i in tr_i], labels[tr_i], [bags[i] for i in va_i], labels[va_i],
@@ -184,6 +187,26 @@ def test_configs4_pipeline_vit_tokens_to_teacher_to_heterophily_aware_gnn():
     outs = [pipeline.collect_teacher_outputs_device(teacher, tokens[idx], labels[idx], [ids[i] for i in idx], dev)
             for idx in (tr_i, va_i)]
     assert outs[0].x.is_cuda and outs[0].knn.shape == (20, 196, 16)
+    assert outs[0].x.data_ptr() == tokens[tr_i].data_ptr() or torch.equal(outs[0].x, tokens[tr_i])
+    # ---- the hand-over vs the CPU path (oracle) on the same tokens and the trained teacher
+    from oracle import graphs as ographs, mil as omil
+    p = {k: v.detach().float().cpu() for k, v in teacher.state_dict().items()}
+    tok_cpu = tokens.cpu()
+    for j, i in enumerate(tr_i[:6]):
+        o = omil.teacher_forward(p, tok_cpu[i])
+        assert float((outs[0].patch_probs[j].cpu() - o["patch_probs"]).abs().max()) < 5e-5
+        assert float((outs[0].attention[j].cpu() - o["attention"]).abs().max()) < 5e-5 * float(o["attention"].max()) + 1e-7
+        assert torch.equal(outs[0].dominant_class[j].cpu().long(), o["patch_probs"].argmax(dim=1))
+        # k-NN: the oracle's neighbour lists; a row may differ only where two candidates are within fp32 noise of a tie
+        nn_ref = ographs.knn_edge_index(tok_cpu[i], 8)[1].view(196, 8)
+        nn_got = outs[0].knn[j, :, :8].cpu().long()
+        rows_off = (nn_ref != nn_got).any(dim=1)
+        if bool(rows_off.any()):
+            d = ographs.pairwise_sqdist(tok_cpu[i])
+            for r in torch.nonzero(rows_off).flatten().tolist():
+                assert set(nn_ref[r].tolist()) == set(nn_got[r].tolist()) or \
+                    float((d[r, nn_ref[r]] - d[r, nn_got[r]]).abs().max()) < 1e-3 * float(d[r, nn_ref[r]].max()), (i, r)
+        assert float(rows_off.float().mean()) < 0.02
     ei = outs[0].knn_edge_index(8)
     het = mh.compute_edge_heterophily_batch([b for b in outs[0].x.cpu().numpy()], [p for p in outs[0].patch_probs.cpu().numpy()],
                                             [d for d in outs[0].dominant_class.cpu().numpy()], [e for e in ei.cpu().numpy()], device=DEV)

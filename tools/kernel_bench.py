@@ -75,7 +75,8 @@ def main():
     so = torch.empty(N, 112, 112, 64, device=DEV, dtype=BF)
     sdw = torch.zeros(64, 3, 7, 7, device=DEV).contiguous(memory_format=torch.channels_last)
     t1 = timeit(lambda: call("isic_conv_stem_fwd_bf16", x4, ws, so, N, 224, 224, 112, 112), a.iters)
-    t2 = timeit(lambda: call("isic_conv_stem_wgrad_bf16", x4, so, sdw, N, 224, 224, 112, 112), a.iters)
+    wsp = torch.empty(call("isic_conv_stem_wgrad_workspace_bytes"), device=DEV, dtype=torch.uint8)
+    t2 = timeit(lambda: call("isic_conv_stem_wgrad_bf16", x4, so, sdw, N, 224, 224, 112, 112, wsp, wsp.numel()), a.iters)
     gfs = 2.0 * N * 112 * 112 * 64 * 147 / 1e9
     print(f"stem fwd {t1:.3f} ms ({gfs / t1:.0f} TF/s alg)  stem wgrad {t2:.3f} ms ({gfs / t2:.0f} TF/s alg)")
     # BN passes on the layer1 activation (N x 56 x 56 x 64)

@@ -42,6 +42,7 @@ def main():
     dw = torch.zeros(64, 3, 7, 7, device=DEV).contiguous(memory_format=torch.channels_last)
     dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     gb_full, gb_pool = y0.numel() * 2 / 1e9, p.numel() * 2 / 1e9
+    wsp = torch.empty(call("isic_conv_stem_wgrad_workspace_bytes"), device=DEV, dtype=torch.uint8)
     rows = [
         ("bn+relu+maxpool fwd (+argmax, +x_sel)", gb_full + 2.5 * gb_pool,
          lambda: call("isic_bn_relu_maxpool3x3s2_fwd_sel_bf16", y0, scale, shift, p, am, xs, N, Ho, Wo, C, Hp, Wp)),
@@ -53,10 +54,10 @@ def main():
          lambda: call("isic_bn_bwd_apply_pooled_bf16", am, gp, y0, mean, rstd, gamma, acc[0], acc[1], N, Ho, Wo, C, Hp, Wp,
                       scale, shift, dy, dg, db)),
         ("stem wgrad from dY (old)", gb_full + x4.numel() * 2 / 1e9,
-         lambda: call("isic_conv_stem_wgrad_bf16", x4, dy, dw, N, H, W, Ho, Wo)),
+         lambda: call("isic_conv_stem_wgrad_bf16", x4, dy, dw, N, H, W, Ho, Wo, wsp, wsp.numel())),
         ("stem wgrad from pooled gradient (new)", gb_full + 1.5 * gb_pool + x4.numel() * 2 / 1e9,
          lambda: call("isic_conv_stem_wgrad_bn_pooled_bf16", x4, y0, am, gp, mean, rstd, gamma, scale, shift, acc[0], acc[1],
-                      dw, dg, db, N, H, W, Ho, Wo, Hp, Wp)),
+                      dw, dg, db, N, H, W, Ho, Wo, Hp, Wp, wsp, wsp.numel())),
     ]
     for name, gb, fn in rows:
         t = timeit(fn)
