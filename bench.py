@@ -417,9 +417,10 @@ def run_gnn(args, world, rank, dev):
         xb, ob, gb = store.batch(idx_static)
         opt.zero_grad()
         sync.reset()
-        probs, _ = model(xb, offsets=ob, graph=gb)
-        loss = ops.cross_entropy_from_probs(probs, store.y_dev[idx_static])
-        loss.backward()
+        with ops.fused_grad_accumulation():              # parameter gradients are added into the flat buffer by the kernels
+            probs, _ = model(xb, offsets=ob, graph=gb)
+            loss = ops.cross_entropy_from_probs(probs, store.y_dev[idx_static])
+            loss.backward()
         sync.finish()
         opt.step(grad_scale=1.0 / world)
         if clock is not None:

@@ -11,6 +11,7 @@
 // and for B alike (any permutation of k is a valid summation order as long as
 // both operands use it).
 #include "common.h"
+#include "../../include/isic_hip_test.h"
 
 // persistent LDS-DMA kernel for the large products (gemm_f32p.hip); ISIC_ERR_UNSUPPORTED = "not for this shape"
 size_t isic_gemm_f32p_workspace_bytes(int transA, int transB, int M, int N, int K);
@@ -31,6 +32,7 @@ struct GemmArgs {
   int transA, transB, act, vecA, vecB;
   float beta;
   int ksplit, klen;     // blockIdx.z handles k in [z*klen, (z+1)*klen): partial sums are atomically added to a pre-scaled C
+  float* partial;       // ... or, with a workspace, stored as [ksplit][M][N] and added in split order by gemm_split_reduce_kernel
 };
 
 // Load 4 consecutive elements (along the contiguous dim) of a row-major matrix
@@ -130,11 +132,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
         if (a.act == ISIC_ACT_RELU) v = fmaxf(v, 0.f);
         else if (a.act == ISIC_ACT_TANH) v = tanhf(v);
         float* cp = a.C + (size_t)row * a.ldc + col;
-        if (a.ksplit > 1) { atomicAdd(cp, v); continue; }      // C already holds beta * C (gemm_scale_kernel)
+        if (a.ksplit > 1) {
+          if (a.partial) a.partial[((size_t)blockIdx.z * a.M + row) * a.N + col] = v;      // deterministic: own slot
+          else atomicAdd(cp, v);                               // C already holds beta * C (gemm_scale_kernel)
+          continue;
+        }
         if (a.beta != 0.f) v += a.beta * (*cp);
         *cp = v;
       }
     }
+}
+
+// C = beta * C + sum over the splits, in split order (split-K happens without bias / activation only)
+__global__ void gemm_split_reduce_kernel(const float* __restrict__ partial, int splits, float* __restrict__ C, int M, int N,
+                                         int ldc, float beta) {
+  const int64_t n = (int64_t)M * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += partial[(size_t)z * n + i];
+    float* p = C + (i / N) * ldc + (i % N);
+    *p = beta != 0.f ? beta * (*p) + s : s;
+  }
 }
 
 // C[M,N] *= beta (0: zero fill) ahead of a split-K accumulation
@@ -260,6 +278,20 @@ __global__ void relu_dropout_bwd_kernel(const float* __restrict__ y, float* __re
   for (; i < n; i += stride) dy[i] = y[i] > 0.f ? dy[i] * scale : 0.f;
 }
 
+// split K when a long reduction meets a small output (weight gradients dW = dY^T X over all the nodes of a batch):
+// a handful of 64x64 tiles would otherwise walk tens of thousands of k on a handful of CUs
+inline int small_split_plan(int M, int N, int K, bool plain, int* klen) {
+  *klen = ((K + BK - 1) / BK) * BK;
+  const long long tiles = (long long)ceil_div(M, BM) * ceil_div(N, BN);
+  if (!plain || K < 2048 || tiles >= 512) return 1;
+  long long want = (1024 + tiles - 1) / tiles;                     // ~4 blocks per CU
+  const long long max_split = K / 256;                             // at least 256 k per split
+  if (want > max_split) want = max_split;
+  if (want <= 1) return 1;
+  *klen = (int)(((K + want - 1) / want + BK - 1) / BK) * BK;
+  return ceil_div(K, *klen);
+}
+
 inline int grid_for(int64_t n, int block) {
   int64_t g = (n + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -270,7 +302,13 @@ inline int grid_for(int64_t n, int block) {
 extern "C" {
 
 size_t isic_gemm_f32_workspace_bytes(int transA, int transB, int M, int N, int K) {
-  return isic_gemm_f32p_workspace_bytes(transA, transB, M, N, K);
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const size_t p = isic_gemm_f32p_workspace_bytes(transA, transB, M, N, K);
+  // the 64 x 64 kernel's own split-K (small_split_plan: a long reduction onto < 512 tiles, no bias / activation)
+  int klen = 0;
+  const int ks = small_split_plan(M, N, K, true, &klen);
+  const size_t q = ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
+  return p > q ? p : q;
 }
 
 int isic_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
@@ -281,15 +319,22 @@ int isic_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, i
 int isic_gemm_f32_ws(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                      float* C, int ldc, const float* bias, int act, float beta, void* workspace, size_t workspace_bytes,
                      void* stream) {
-  ISIC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0);
+  return isic_test_gemm_f32_variant(0, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, beta, workspace,
+                                    workspace_bytes, stream);
+}
+
+int isic_test_gemm_f32_variant(int variant, int transA, int transB, int M, int N, int K, const float* A, int lda,
+                               const float* B, int ldb, float* C, int ldc, const float* bias, int act, float beta,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  ISIC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && variant >= 0 && variant <= 2);
   if (M == 0 || N == 0) return ISIC_OK;
   ISIC_CHECK_ARG(A && B && C);
   ISIC_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N);
   ISIC_CHECK_ARG(act >= ISIC_ACT_NONE && act <= ISIC_ACT_TANH);
-  {
+  if (variant != 1) {
     const int rc = isic_gemm_f32p_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, beta, workspace,
                                          workspace_bytes, as_stream(stream));
-    if (rc != ISIC_ERR_UNSUPPORTED) return rc;             // launched (or failed for real): large, 16-byte friendly products
+    if (rc != ISIC_ERR_UNSUPPORTED || variant == 2) return rc;   // launched (or failed for real): large, 16-byte friendly products
   }
   GemmArgs a;
   a.A = A; a.B = B; a.C = C; a.bias = bias;
@@ -299,26 +344,20 @@ int isic_gemm_f32_ws(int transA, int transB, int M, int N, int K, const float* A
   a.vecB = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
   dim3 grid(ceil_div(M, BM), ceil_div(N, BN));
   ISIC_CHECK_ARG(grid.y <= 65535u);
-  // split K when a long reduction meets a small output (weight gradients dW = dY^T X over all the nodes of a batch):
-  // a handful of 64x64 tiles would otherwise walk tens of thousands of k on a handful of CUs
-  a.ksplit = 1; a.klen = ((K + BK - 1) / BK) * BK;
-  const long long tiles = (long long)grid.x * grid.y;
-  if (!bias && act == ISIC_ACT_NONE && K >= 2048 && tiles < 512) {
-    long long want = (1024 + tiles - 1) / tiles;                   // ~4 blocks per CU
-    const long long max_split = K / 256;                           // at least 256 k per split
-    if (want > max_split) want = max_split;
-    if (want > 1) {
-      a.klen = (int)(((K + want - 1) / want + BK - 1) / BK) * BK;
-      a.ksplit = ceil_div(K, a.klen);
-    }
-  }
+  a.ksplit = small_split_plan(M, N, K, !bias && act == ISIC_ACT_NONE, &a.klen);
+  a.partial = nullptr;
   if (a.ksplit > 1) {
-    if (beta != 1.f)
+    if (workspace && workspace_bytes >= (size_t)a.ksplit * M * N * sizeof(float))
+      a.partial = reinterpret_cast<float*>(workspace);           // deterministic: per-split partials, added in order below
+    else if (beta != 1.f)
       hipLaunchKernelGGL(gemm_scale_kernel, dim3(grid_for((int64_t)M * N, 256)), dim3(256), 0, as_stream(stream), C, M, N,
                          ldc, beta);
     grid.z = a.ksplit;
   }
   hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, as_stream(stream), a);
+  if (a.partial)
+    hipLaunchKernelGGL(gemm_split_reduce_kernel, dim3(grid_for((int64_t)M * N, 256)), dim3(256), 0, as_stream(stream),
+                       a.partial, a.ksplit, C, M, N, ldc, beta);
   return isic_launch_status();
 }
 

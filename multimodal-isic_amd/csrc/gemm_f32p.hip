@@ -317,6 +317,11 @@ static G32Plan g32_plan(int transA, int transB, int M, int N, int K) {
   p.mtiles = ceil_div(Mr, PM);
   p.nslices = ceil_div(Nr, PN);
   const int Ktiles = ceil_div(K, PK);
+  // measured against the 64 x 64 x 16 kernel at 50 176 rows (tools/gemm_bench.py, profiles/r03_gemm_bench.txt): the 256-row
+  // tile loses when the output has fewer than 192 rows (half of every tile is empty: 128 x 128 x 50 176 ran 88 vs 51 us) and
+  // when a short reduction (K = 128: 4 K-tiles per tile) meets several column slices (196 x 4 work items quantise badly
+  // over 256 CUs: 115 vs 108 us); it wins 1.15-1.55x everywhere else
+  if (Mr < 192 || (Ktiles < 8 && p.nslices > 1)) { p.ok = false; return p; }
   const int cus = isic_cu_count();
   const int tiles = p.mtiles * p.nslices;
   p.splits = 1;

@@ -57,6 +57,43 @@ def _f32c(t):
     return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
 
 
+# --------------------------------------------------------------------------- gradient accumulation inside the kernels
+_FUSED_ACC = False
+
+
+class fused_grad_accumulation:
+    """Inside this context the backward of ``linear`` / ``layer_norm`` ADDS a parameter's gradient into its existing
+    ``.grad`` buffer in the producing kernel's epilogue (GEMM with beta = 1, the column sums and LayerNorm's dgamma / dbeta
+    likewise) and hands autograd ``None`` -- instead of materialising the gradient and letting AccumulateGrad launch one
+    tiny add kernel per parameter (~30 per GraphMIL step, each bound by launch latency).  Meant for the train loops,
+    where every parameter is a view into the optimizer's flat gradient buffer that ``zero_grad`` has zeroed
+    (`05_train_gnns.py:341-346`: zero_grad -> backward -> step); only ``loss.backward()`` semantics are preserved
+    (``torch.autograd.grad`` would not see these gradients)."""
+
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        global _FUSED_ACC
+        self.prev, _FUSED_ACC = _FUSED_ACC, self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        global _FUSED_ACC
+        _FUSED_ACC = self.prev
+        return False
+
+
+def _acc_target(p):
+    """The buffer a backward kernel may accumulate into directly, or None."""
+    if not _FUSED_ACC or not isinstance(p, torch.nn.Parameter):
+        return None
+    g = p.grad
+    if g is None or not g.is_cuda or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape:
+        return None
+    return g
+
+
 # --------------------------------------------------------------------------- raw helpers (no autograd)
 def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, out=None, beta=0.0):
     """out[M,N] = act(op(a) @ op(b) + bias) + beta*out   (fp32 MFMA)."""
@@ -122,6 +159,7 @@ class LinearFn(torch.autograd.Function):
             y = gemm(x2, w, trans_b=True, bias=b, act=act)
         ctx.act, ctx.drop_scale, ctx.has_bias = act, (drop.scale if drop.active else 1.0), bias is not None
         ctx.xshape = x.shape
+        ctx.params = (weight, bias)              # the Parameters themselves: fused_grad_accumulation adds into their .grad
         ctx.save_for_backward(x2, w, y if act != ACT_NONE else None)
         return y.reshape(*x.shape[:-1], w.shape[0])
 
@@ -139,10 +177,19 @@ class LinearFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = gemm(g, w).reshape(ctx.xshape)
+        wp, bp = ctx.params
         if ctx.needs_input_grad[1]:
-            dw = gemm(g, x2, trans_a=True)
+            tgt = _acc_target(wp)
+            if tgt is not None:
+                gemm(g, x2, trans_a=True, out=tgt, beta=1.0)
+            else:
+                dw = gemm(g, x2, trans_a=True)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(g)
+            tgt = _acc_target(bp)
+            if tgt is not None:
+                colsum(g, out=tgt, beta=1.0)
+            else:
+                db = colsum(g)
         return dx, dw, db, None, None
 
 
@@ -273,6 +320,7 @@ class LayerNormFn(torch.autograd.Function):
         ctx.cfg = (M, N, int(relu), drop)
         ctx.has_res = residual is not None
         ctx.xshape = x.shape
+        ctx.params = (gamma, beta)
         ctx.save_for_backward(x2, g, b, mean, rstd)
         return y.reshape(x.shape)
 
@@ -282,11 +330,13 @@ class LayerNormFn(torch.autograd.Function):
         M, N, relu, drop = ctx.cfg
         dy2 = _f32c(dy.reshape(M, N))
         dx = torch.empty_like(x2)
-        dg = torch.zeros((N,), device=x2.device, dtype=torch.float32)
-        db = torch.zeros((N,), device=x2.device, dtype=torch.float32)
+        tg, tb = _acc_target(ctx.params[0]), _acc_target(ctx.params[1])
+        fused = tg is not None and tb is not None      # the kernel ACCUMULATES (+=) into dgamma / dbeta
+        dg = tg if fused else torch.zeros((N,), device=x2.device, dtype=torch.float32)
+        db = tb if fused else torch.zeros((N,), device=x2.device, dtype=torch.float32)
         call("isic_layernorm_bwd_clk", dy2, x2, g, b, mean, rstd, dx, dg, db, M, N, relu, drop.threshold, drop.scale,
              drop.seed, drop.stream, drop.clock)
-        return dx.reshape(ctx.xshape), dg, db, (dy if ctx.has_res else None), None, None, None
+        return dx.reshape(ctx.xshape), (None if fused else dg), (None if fused else db), (dy if ctx.has_res else None), None, None, None
 
 
 def layer_norm(x, gamma, beta, eps=1e-5, relu=False, drop=None, residual=None):

@@ -260,25 +260,28 @@ def test_training_step_is_bit_reproducible(images):
     assert all(bool(torch.isfinite(v).all()) and float(v.abs().max()) > 0 for v in g1.values())
 
 
-def _ref_block(x, P, stride, ds):
+def _ref_block(x, P, stride, ds, forced=None):
     """torch-CPU fp32 restatement of one BasicBlock with the HIP path's bf16 rounding points (the dataflow of
-    test_block_backward_teacher_forced, as a function): returns (out, backward) with backward(gout) -> (dx, grads)."""
+    test_block_backward_teacher_forced, as a function): returns (out, backward) with backward(gout) -> (dx, grads).
+    ``forced`` = the HIP block's own saved forward tensors (c1, a1, c2, out, cd as NCHW fp32): the forward is then TAKEN
+    from the HIP path (teacher forcing) and only the backward is restated -- the comparison is not blurred by the
+    forward's rounding flips."""
     from torch.nn.grad import conv2d_input, conv2d_weight
     v = lambda t: t.view(1, -1, 1, 1)
     w1, w2 = P["conv1.weight"], P["conv2.weight"]
-    c1 = _rb(F.conv2d(x, w1, None, stride, 1))
+    c1 = forced["c1"] if forced else _rb(F.conv2d(x, w1, None, stride, 1))
     m1, r1, sc1, sh1 = _bn_stats(c1, P["bn1.weight"], P["bn1.bias"])
     pre1 = c1 * v(sc1) + v(sh1)
-    a1 = _rb(torch.relu(pre1))
-    c2 = _rb(F.conv2d(a1, w2, None, 1, 1))
+    a1 = forced["a1"] if forced else _rb(torch.relu(pre1))
+    c2 = forced["c2"] if forced else _rb(F.conv2d(a1, w2, None, 1, 1))
     m2, r2, sc2, sh2 = _bn_stats(c2, P["bn2.weight"], P["bn2.bias"])
     idn = x
     if ds:
         wd = P["downsample.0.weight"]
-        cd = _rb(F.conv2d(x, wd, None, stride, 0))
+        cd = forced["cd"] if forced else _rb(F.conv2d(x, wd, None, stride, 0))
         md, rd, scd, shd = _bn_stats(cd, P["downsample.1.weight"], P["downsample.1.bias"])
         idn = _rb(cd * v(scd) + v(shd))
-    out = _rb(torch.relu(c2 * v(sc2) + v(sh2) + idn))
+    out = forced["out"] if forced else _rb(torch.relu(c2 * v(sc2) + v(sh2) + idn))
 
     def backward(gout):
         G = {}
@@ -302,11 +305,15 @@ def _ref_block(x, P, stride, ds):
 
 def test_three_block_chain_backward():
     """the COMPOSITION of blocks -- layer1.1 -> layer2.0 (stride 2 + 1x1 downsample) -> layer2.1 run as
-    a chain, forward and backward, on the HIP path against the same chain of torch-CPU fp32 blocks that round to bf16 at
-    the same points.  Unlike the per-block test nothing is re-injected between blocks: block i's dx is block i-1's
-    upstream gradient, the residual-gradient joins and the 64 -> 128 channel / stride-2 hand-over are inside the
-    comparison.  <= 3 % (norm-wise) for the input gradient of the chain and every parameter gradient of the three blocks,
-    <= 1 % for the chain's output."""
+    a chain on the HIP path, forward and backward, against a chain of torch-CPU fp32 blocks that round to bf16 at the same
+    points.  Two references:
+      * free-running: the reference chain computes its own forward.  Its activations differ from the HIP chain's by
+        rounding flips (<= 1 % of the output after three blocks), which the ReLU masks and BatchNorm statistics of the
+        backward amplify: every gradient within 8 % (measured 5-6 %);
+      * forward teacher-forced, backward free-running: every reference block takes its forward tensors from the HIP
+        chain, but the BACKWARD runs as a chain -- block i's dx is block i-1's upstream gradient, the residual-gradient
+        joins and the 64 -> 128 channel / stride-2 hand-over are inside the comparison and nothing is re-injected between
+        blocks: <= 3 % (norm-wise) for the chain's input gradient and every parameter gradient of the three blocks."""
     from isic_hip.encoder import ResNet18Encoder
     chain = [("layer1.1", 64, 64, 1), ("layer2.0", 64, 128, 2), ("layer2.1", 128, 128, 1)]
     N, H = 12, 24
@@ -335,19 +342,6 @@ def test_three_block_chain_backward():
             Ps.append(P)
             names_all.append(names)
     x = _rb(torch.relu(torch.randn(N, 64, H, H, generator=g)))
-    # ---- reference chain
-    t, bwds = x, []
-    for (pre, cin, planes, stride), P in zip(chain, Ps):
-        t, b = _ref_block(t, P, stride, stride != 1 or cin != planes)
-        bwds.append(b)
-    out_ref = t
-    gout = _rb(1.0 + 0.5 * torch.randn(out_ref.shape, generator=g))
-    gr, Gs = gout, []
-    for b in reversed(bwds):
-        gr, G = b(gr)
-        Gs.append(G)
-    Gs.reverse()
-    dx_ref = gr
     # ---- HIP chain
     enc.prepare_weights()
     enc._arena_reset(torch.device(DEV))
@@ -355,7 +349,8 @@ def test_three_block_chain_backward():
     for pre, cin, planes, stride in chain:
         h, s = enc.block_forward(h, pre, stride != 1 or cin != planes)
         saved.append(s)
-    assert _rel(h.float().cpu().permute(0, 3, 1, 2), out_ref) < 0.01
+    out_hip = h.float().cpu().permute(0, 3, 1, 2)
+    gout = _rb(1.0 + 0.5 * torch.randn(out_hip.shape, generator=g))
     for names in names_all:
         for k in names:
             enc._get(k).grad = None
@@ -364,9 +359,34 @@ def test_three_block_chain_backward():
     for (pre, cin, planes, stride), s in zip(reversed(chain), reversed(saved)):
         gd, _ = enc.block_backward(gd, pre, stride != 1 or cin != planes, s)
     torch.cuda.synchronize()
-    errs = {"dx": _rel(gd.float().cpu().permute(0, 3, 1, 2), dx_ref)}
-    for (pre, *_), names, G in zip(chain, names_all, Gs):
-        for k in names:
-            errs[k] = _rel(enc._get(k).grad.cpu(), G[k[len(pre) + 1:]])
-    bad = {k: round(e, 4) for k, e in errs.items() if e > 0.03}
-    assert not bad, f"3-block chain: relative gradient errors above 3 %: {bad} (all: { {k: round(e, 4) for k, e in errs.items()} })"
+    dx_hip = gd.float().cpu().permute(0, 3, 1, 2)
+    nchw = lambda t: None if t is None else t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+    def reference(forced_mode):
+        t, bwds = x, []
+        for (pre, cin, planes, stride), P, sv in zip(chain, Ps, saved):
+            forced = None
+            if forced_mode:
+                xin, c1, a1, _st1, c2, out, _st2, cd, _std = sv
+                t = nchw(xin)
+                forced = {"c1": nchw(c1), "a1": nchw(a1), "c2": nchw(c2), "out": nchw(out), "cd": nchw(cd)}
+            t, b = _ref_block(t, P, stride, stride != 1 or cin != planes, forced)
+            bwds.append(b)
+        gr, Gs = gout, []
+        for b in reversed(bwds):
+            gr, G = b(gr)
+            Gs.append(G)
+        Gs.reverse()
+        return t, gr, Gs
+
+    for forced_mode, tol in ((False, 0.08), (True, 0.03)):
+        out_ref, dx_ref, Gs = reference(forced_mode)
+        assert _rel(out_hip, out_ref) < 0.01
+        errs = {"dx": _rel(dx_hip, dx_ref)}
+        for (pre, *_), names, G in zip(chain, names_all, Gs):
+            for k in names:
+                errs[k] = _rel(enc._get(k).grad.cpu(), G[k[len(pre) + 1:]])
+        bad = {k: round(e, 4) for k, e in errs.items() if e > tol}
+        what = "forward teacher-forced" if forced_mode else "free-running"
+        print(f"[3-block chain, {what}] max rel err {max(errs.values()):.4f}")
+        assert not bad, f"3-block chain ({what}): relative gradient errors above {tol}: {bad} (all: { {k: round(e, 4) for k, e in errs.items()} })"
