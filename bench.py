@@ -201,7 +201,7 @@ def split_by_class(records, steps):
 
 # ----------------------------------------------------------------------------------------------- configs[1]: MIL
 def run_mil(args, world, rank, dev):
-    from isic_hip import ddp, optim
+    from isic_hip import ddp, ops, optim
     from model import MultiModalMILNet
 
     B, K, S, R, C = args.bags_per_step, args.patches, args.image_size, args.radiomics_dim, 7
@@ -231,9 +231,10 @@ def run_mil(args, world, rank, dev):
         s = i % n_sets
         opt.zero_grad()
         sync.reset()
-        out = model(images[s], radiom[s])
-        loss = model.loss(out, labels[s])
-        loss.backward()
+        with ops.fused_grad_accumulation():          # head gradients are added into the flat buffer by the kernels
+            out = model(images[s], radiom[s])
+            loss = model.loss(out, labels[s])
+            loss.backward()
         sync.finish()
         opt.step(grad_scale=1.0 / world)
         return loss

@@ -253,8 +253,9 @@ def train_milnet_fold(model, train_set, val_set, *, optimizer="adamw", lr=2.2e-4
             sync.reset()
             if mine:
                 img, rad, y = tr.batch(mine)
-                out = model(img, rad)
-                (model.loss(out, y) * (len(mine) * world / len(glob))).backward()
+                with ops.fused_grad_accumulation():
+                    out = model(img, rad)
+                    (model.loss(out, y) * (len(mine) * world / len(glob))).backward()
             _sync_step(opt, sync, world)
         ddp.average_buffers(model)               # BatchNorm running statistics are per rank during the epoch
         probs, val_loss = eval_milnet(model, va)
