@@ -16,7 +16,13 @@
 
 namespace {
 
-constexpr int NWAVE = 4;
+// Waves per bag (round 3; four before): a wave handles one instance row per memory latency, so a 196-node graph on four
+// waves was 49 dependent round trips (121 us forward at 256 graphs = 1.1 TB/s of an 8 TB/s memory).  The backward kernel
+// (61 VGPRs) runs sixteen waves; the forward kernel needs 217 VGPRs (class-space branch), so eight (512 threads).
+constexpr int NWAVE = 8;                   // forward
+constexpr int NTHR = NWAVE * 64;
+constexpr int NWAVE_B = 16;                // backward
+constexpr int NTHR_B = NWAVE_B * 64;
 constexpr int MAX_HEADS = 4;   // heads per launch (host loops over groups of 4)
 constexpr int MAX_C = 16;
 
@@ -31,12 +37,12 @@ struct PoolArgs {
 
 // dynamic LDS carve (floats):
 //   w3s[heads*A] | W4s[C*H] | sc[max_bag*heads] | wm[NWAVE*heads] | wl[NWAVE*heads] |
-//   wP[NWAVE*MAX_C] | wz[NWAVE*heads*H]
+//   wP[NWAVE*MAX_C] | wz[NWAVE*heads*H] | Ms[4] | Ls[4] | fws[4*NWAVE]
 // JA > 0: A <= 64 * JA -- the attention-hidden values of a row (all heads) are fetched up front together with the
 // h values, so that a row costs ONE memory latency instead of one per head and 64-column slice (the generic loop,
 // JA = 0, was latency-bound at an eighth of the HBM rate on GraphMIL's 4 heads x 128).
 template <int JH, int JA>
-__global__ __launch_bounds__(256) void attn_pool_fwd_kernel(PoolArgs a) {
+__global__ __launch_bounds__(NTHR) void attn_pool_fwd_kernel(PoolArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = a.H, A = a.A, NH = a.heads, C = a.C;
   float* w3s = smem;
@@ -46,15 +52,18 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(PoolArgs a) {
   float* wl = wm + NWAVE * NH;
   float* wP = wl + NWAVE * NH;
   float* wz = wP + NWAVE * MAX_C;
+  float* Ms = wz + (size_t)NWAVE * NH * H;       // merged running max / sum per head and the waves' rescale factors
+  float* Ls = Ms + MAX_HEADS;
+  float* fws = Ls + MAX_HEADS;                   // [MAX_HEADS][NWAVE]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
   const int64_t lo = a.offsets[b], hi = a.offsets[b + 1];
   const int nb = (int)(hi - lo);
 
-  for (int i = tid; i < NH * A; i += 256) w3s[i] = a.w3[(size_t)a.head0 * A + i];
+  for (int i = tid; i < NH * A; i += NTHR) w3s[i] = a.w3[(size_t)a.head0 * A + i];
   if (a.W4)
-    for (int i = tid; i < C * H; i += 256) W4s[i] = a.W4[i];
+    for (int i = tid; i < C * H; i += NTHR) W4s[i] = a.W4[i];
   __syncthreads();
 
   float m[MAX_HEADS], l[MAX_HEADS], zacc[MAX_HEADS][JH], accP[MAX_C];
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(PoolArgs a) {
     }
   }
 
-  // ---- merge the 4 waves
+  // ---- merge the waves
   if (lane == 0) {
 #pragma unroll
     for (int k = 0; k < MAX_HEADS; ++k) if (k < NH) { wm[wave * NH + k] = m[k]; wl[wave * NH + k] = l[k]; }
@@ -166,40 +175,35 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(PoolArgs a) {
     }
   }
   __syncthreads();
-  float M[MAX_HEADS], L[MAX_HEADS], fw[MAX_HEADS][NWAVE];
-#pragma unroll
-  for (int k = 0; k < MAX_HEADS; ++k) {
-    M[k] = -INFINITY; L[k] = 0.f;
-    if (k < NH) {
-#pragma unroll
-      for (int w = 0; w < NWAVE; ++w) M[k] = fmaxf(M[k], wm[w * NH + k]);
-#pragma unroll
-      for (int w = 0; w < NWAVE; ++w) {
-        const float mw = wm[w * NH + k];
-        fw[k][w] = (mw == -INFINITY) ? 0.f : expf(mw - M[k]);
-        L[k] += wl[w * NH + k] * fw[k][w];
-      }
+  // merge factors, once per head (LDS): with sixteen waves a per-thread copy of fw[heads][waves] spilled to scratch
+  if (tid < NH) {
+    const int k = tid;
+    float M = -INFINITY, L = 0.f;
+    for (int w = 0; w < NWAVE; ++w) M = fmaxf(M, wm[w * NH + k]);
+    for (int w = 0; w < NWAVE; ++w) {
+      const float mw = wm[w * NH + k];
+      const float f = (mw == -INFINITY) ? 0.f : expf(mw - M);
+      fws[k * NWAVE + w] = f;
+      L += wl[w * NH + k] * f;
     }
+    Ms[k] = M; Ls[k] = L;
   }
+  __syncthreads();
   // attention weights
-  for (int i = tid; i < nb * NH; i += 256) {
+  for (int i = tid; i < nb * NH; i += NTHR) {
     const int n = i / NH, k = i - n * NH;
-    float Mk = 0.f, Lk = 1.f;
-#pragma unroll
-    for (int kk = 0; kk < MAX_HEADS; ++kk) if (kk == k) { Mk = M[kk]; Lk = L[kk]; }
-    a.att[(size_t)(lo + n) * a.heads_total + a.head0 + k] = expf(sc[i] - Mk) / Lk;
+    a.att[(size_t)(lo + n) * a.heads_total + a.head0 + k] = expf(sc[i] - Ms[k]) / Ls[k];
   }
   // pooled features: mean over ALL heads of sum_n a*h
   if (a.z) {
     const float inv_heads = 1.f / (float)a.heads_total;
-    for (int col = tid; col < H; col += 256) {
+    for (int col = tid; col < H; col += NTHR) {
       float zs = 0.f;
-#pragma unroll
-      for (int k = 0; k < MAX_HEADS; ++k) if (k < NH && nb > 0) {
+      for (int k = 0; k < NH; ++k) if (nb > 0) {
         float zk = 0.f;
 #pragma unroll
-        for (int w = 0; w < NWAVE; ++w) zk += wz[(w * NH + k) * H + col] * fw[k][w];
-        zs += zk / L[k];
+        for (int w = 0; w < NWAVE; ++w) zk += wz[(w * NH + k) * H + col] * fws[k * NWAVE + w];
+        zs += zk / Ls[k];
       }
       zs *= inv_heads;
       float* zp = a.z + (size_t)b * H + col;
@@ -214,8 +218,8 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(PoolArgs a) {
       if (c < C) {
         if (nb > 0) {
 #pragma unroll
-          for (int w = 0; w < NWAVE; ++w) bl[c] += wP[w * MAX_C + c] * fw[0][w];
-          bl[c] /= L[0];
+          for (int w = 0; w < NWAVE; ++w) bl[c] += wP[w * MAX_C + c] * fws[w];
+          bl[c] /= Ls[0];
         }
         a.bag_logits[(size_t)b * C + c] = bl[c];
         mx = fmaxf(mx, bl[c]);
@@ -239,11 +243,11 @@ struct PoolBwdArgs {
   float* d_h; int accumulate_dh; float* d_u; float* d_s; float* d_P;
 };
 
-// LDS (floats): w3s[heads*A] | W4s[C*H] | dzs[H] | da[max_bag*heads] | red[NWAVE*heads]
+// LDS (floats): w3s[heads*A] | W4s[C*H] | dzs[H] | da[max_bag*heads] | red[NWAVE_B*heads]
 // FAST: H <= 128 and A <= 128 -- the h / attention-hidden values of a row are fetched up front (two per lane and head)
 // instead of through runtime-length loops of dependent loads (as attn_pool_fwd_kernel<JH, 2>)
 template <bool FAST>
-__global__ __launch_bounds__(256) void attn_pool_bwd_kernel(PoolBwdArgs a) {
+__global__ __launch_bounds__(NTHR_B) void attn_pool_bwd_kernel(PoolBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = a.H, A = a.A, NH = a.heads, C = a.C;
   float* w3s = smem;
@@ -257,10 +261,10 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(PoolBwdArgs a) {
   const int nb = (int)(hi - lo);
   const float inv_heads = 1.f / (float)NH;
 
-  for (int i = tid; i < NH * A; i += 256) w3s[i] = a.w3[i];
+  for (int i = tid; i < NH * A; i += NTHR_B) w3s[i] = a.w3[i];
   if (a.W4)
-    for (int i = tid; i < C * H; i += 256) W4s[i] = a.W4[i];
-  for (int i = tid; i < H; i += 256) dzs[i] = a.d_z ? a.d_z[(size_t)b * H + i] : 0.f;
+    for (int i = tid; i < C * H; i += NTHR_B) W4s[i] = a.W4[i];
+  for (int i = tid; i < H; i += NTHR_B) dzs[i] = a.d_z ? a.d_z[(size_t)b * H + i] : 0.f;
   float dL[MAX_C];
 #pragma unroll
   for (int c = 0; c < MAX_C; ++c) dL[c] = (a.d_bag_logits && c < C) ? a.d_bag_logits[(size_t)b * C + c] : 0.f;
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(PoolBwdArgs a) {
   float dot[MAX_HEADS];
 #pragma unroll
   for (int k = 0; k < MAX_HEADS; ++k) dot[k] = 0.f;
-  for (int n = wave; n < nb; n += NWAVE) {
+  for (int n = wave; n < nb; n += NWAVE_B) {
     float base = 0.f;
     if (a.d_z) {
       const float* hrow = a.h + (size_t)(lo + n) * H;
@@ -304,12 +308,15 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(PoolBwdArgs a) {
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < MAX_HEADS; ++k) if (k < NH) {
-    dot[k] = (red[0 * NH + k] + red[1 * NH + k]) + (red[2 * NH + k] + red[3 * NH + k]);
+    float d = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWAVE_B; ++w) d += red[w * NH + k];          // fixed order
+    dot[k] = d;
   }
 
   // pass 2
   const int At = NH * A;
-  for (int n = wave; n < nb; n += NWAVE) {
+  for (int n = wave; n < nb; n += NWAVE_B) {
     float an[MAX_HEADS], ds[MAX_HEADS];
 #pragma unroll
     for (int k = 0; k < MAX_HEADS; ++k) {
@@ -406,12 +413,13 @@ int isic_attn_pool_fwd(const float* h, const float* t, const float* w3, const fl
     a.att = att; a.z = z; a.patch_logits = patch_logits; a.patch_probs = patch_probs;
     a.bag_logits = bag_logits; a.bag_probs = bag_probs; a.z_accumulate = head0 > 0;
     const size_t lds = sizeof(float) * ((size_t)nh * A + (W4 ? (size_t)C * H : 0) + (size_t)max_bag * nh +
-                                        2 * NWAVE * nh + NWAVE * MAX_C + (size_t)NWAVE * nh * H);
+                                        2 * NWAVE * nh + NWAVE * MAX_C + (size_t)NWAVE * nh * H + 2 * MAX_HEADS +
+                                        MAX_HEADS * NWAVE);
     int rc;
 #define LAUNCH_POOL(JH, JA)                                                                         \
   rc = ensure_lds(attn_pool_fwd_kernel<JH, JA>, lds);                                               \
   if (rc != ISIC_OK) return rc;                                                                     \
-  hipLaunchKernelGGL((attn_pool_fwd_kernel<JH, JA>), dim3(B), dim3(256), lds, as_stream(stream), a)
+  hipLaunchKernelGGL((attn_pool_fwd_kernel<JH, JA>), dim3(B), dim3(NTHR), lds, as_stream(stream), a)
     if (H <= 128 && A <= 128) { LAUNCH_POOL(2, 2); }
     else if (H <= 128) { LAUNCH_POOL(2, 0); }
     else if (H <= 256) { LAUNCH_POOL(4, 0); }
@@ -439,16 +447,16 @@ int isic_attn_pool_bwd(const float* h, const float* t, const float* att, const f
   a.d_bag_logits = d_bag_logits; a.d_z = d_z; a.d_h = d_h; a.accumulate_dh = accumulate_dh;
   a.d_u = d_u; a.d_s = d_s; a.d_P = d_P;
   const size_t lds = sizeof(float) * ((size_t)heads * A + (W4 ? (size_t)C * H : 0) + H + (size_t)max_bag * heads +
-                                      NWAVE * heads);
+                                      NWAVE_B * heads);
   int rc;
   if (H <= 128 && A <= 128) {
     rc = ensure_lds(attn_pool_bwd_kernel<true>, lds);
     if (rc != ISIC_OK) return rc;
-    hipLaunchKernelGGL(attn_pool_bwd_kernel<true>, dim3(B), dim3(256), lds, as_stream(stream), a);
+    hipLaunchKernelGGL(attn_pool_bwd_kernel<true>, dim3(B), dim3(NTHR_B), lds, as_stream(stream), a);
   } else {
     rc = ensure_lds(attn_pool_bwd_kernel<false>, lds);
     if (rc != ISIC_OK) return rc;
-    hipLaunchKernelGGL(attn_pool_bwd_kernel<false>, dim3(B), dim3(256), lds, as_stream(stream), a);
+    hipLaunchKernelGGL(attn_pool_bwd_kernel<false>, dim3(B), dim3(NTHR_B), lds, as_stream(stream), a);
   }
   return isic_launch_status();
 }

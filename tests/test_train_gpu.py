@@ -345,11 +345,27 @@ def test_milnet_training_auroc_parity(depth):
     assert gap_b <= 0.002, (depth, gap_b, auc_b, hist[-1]["val_auc"])
     assert pgap_b <= 0.01 and abs(loss_b - hist[-1]["val_loss"]) < 0.01 * hist[-1]["val_loss"], (depth, pgap_b, loss_b)
     # the running BatchNorm statistics the HIP loop's evaluation used follow the oracle's (norm-wise: they are part of the
-    # diverging trajectory, single channels move by ~10 % after 40 chaotic steps)
+    # diverging trajectory -- single layers move by ~10 % after 40 chaotic steps; the update RULE is pinned below)
     sdh = net.state_dict()
     for k, v in running.items():
         got = sdh["encoder." + k].cpu()
-        assert float((got - v).norm()) <= 0.10 * float(v.norm()) + 1e-2, k
+        assert float((got - v).norm()) <= 0.25 * float(v.norm()) + 1e-2, k
+    # ... and the update rule itself (momentum 0.1, unbiased variance), without chaos: ONE training forward from the same
+    # initial parameters on the same bags
+    from oracle import model as omodel, resnet as oresnet
+    net3 = MultiModalMILNet(hidden_dim=32, att_dim=16, dropout=0.25, radiomics_dim=R, num_classes=C, encoder_layers=layers)
+    net3.load_state_dict({k: v.clone() for k, v in p0.items()}, strict=False)
+    net3 = net3.to(DEV).train()
+    net3.set_dropout_state(seed=321, step=0)
+    img, rad = train_set[0][:14], train_set[1][:14]
+    net3(img.to(DEV), rad.to(DEV))
+    run1 = oresnet.fresh_running(omodel.sub(p0, "encoder"))
+    omodel.milnet_forward(p0, img.reshape(-1, *img.shape[2:]), rad, np.arange(15) * K, emulate_bf16=True, layers=layers,
+                          drop={"seed": 321, "step": 0}, mil_dropout=0.25, running=run1)
+    sd3 = net3.state_dict()
+    for k, v in run1.items():
+        got = sd3["encoder." + k].cpu()
+        assert float((got - v).norm()) <= 0.01 * float(v.norm()) + 1e-4, ("one-step running statistics", k)
 
 
 def test_captured_gnn_step_equals_eager_steps():
