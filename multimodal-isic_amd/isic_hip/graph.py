@@ -77,6 +77,20 @@ def _graph_from_parts(n_nodes, num_edges, mode, parts):
 GraphBatch.from_parts = staticmethod(_graph_from_parts)
 
 
+def _spmm_launch(graph, transposed, x, bias, out, alpha, addend, addend_scale):
+    """One aggregation launch.  A ``GraphBatch`` that knows its graph boundaries (``bag_offsets``: a batch of small graphs,
+    block-diagonal operator -- forward and transposed alike) goes to the graph-resident kernel (``spmm_graph.hip``: a
+    graph's node features staged in LDS once); anything else to the grouped-lane gather."""
+    rp, c, v = (graph.rowptr_t, graph.col_t, graph.val_t) if transposed else (graph.rowptr, graph.col, graph.val)
+    n, F = x.shape
+    offs = getattr(graph, "bag_offsets", None)
+    if offs is not None and offs.total == n and call("isic_spmm_csr_graphs_supported", int(F), int(offs.max_bag)):
+        call("isic_spmm_csr_graphs_f32", rp, c, v, x, bias, out, n, F, alpha, addend, addend_scale, offs.device,
+             int(offs.num_bags), int(offs.max_bag))
+    else:
+        call("isic_spmm_csr_f32", rp, c, v, x, bias, out, n, F, alpha, addend, addend_scale)
+
+
 class SpmmFn(torch.autograd.Function):
     """out = alpha * A^ x (+ bias) (+ addend_scale * addend); backward through the transposed CSR."""
 
@@ -88,8 +102,8 @@ class SpmmFn(torch.autograd.Function):
         if n != graph.n_nodes:
             raise ValueError(f"x has {n} rows, graph has {graph.n_nodes} nodes")
         out = torch.empty_like(x2)
-        call("isic_spmm_csr_f32", graph.rowptr, graph.col, graph.val, x2, _f32c(bias) if bias is not None else None, out,
-             n, F, float(alpha), _f32c(addend) if addend is not None else None, float(addend_scale))
+        _spmm_launch(graph, False, x2, _f32c(bias) if bias is not None else None, out, float(alpha),
+                     _f32c(addend) if addend is not None else None, float(addend_scale))
         ctx.graph, ctx.alpha, ctx.addend_scale = graph, float(alpha), float(addend_scale)
         ctx.has_bias, ctx.has_addend = bias is not None, addend is not None
         return out
@@ -101,8 +115,7 @@ class SpmmFn(torch.autograd.Function):
         dx = db = da = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(dy)
-            call("isic_spmm_csr_f32", g.rowptr_t, g.col_t, g.val_t, dy, None, dx, dy.shape[0], dy.shape[1], ctx.alpha,
-                 None, 0.0)
+            _spmm_launch(g, True, dy, None, dx, ctx.alpha, None, 0.0)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy)
         if ctx.has_addend and ctx.needs_input_grad[4]:
