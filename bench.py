@@ -167,7 +167,7 @@ def kernel_source_hash(prefixes=None):
 TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 TRAFFIC_SOURCES = {
     "mil": ("conv_igemm", "conv_halo", "conv_pgemm", "conv_c64"),      # kernels behind isic_conv2d_igemm_bf16
-    "gnn": ("graph", "spmm_graph"),                                     # isic_spmm_csr_f32 / isic_spmm_csr_graphs_f32
+    "gnn": ("graph",),                                                  # isic_spmm_csr_f32
     "vit": ("gemm_f16",),                                               # isic_gemm_f16
 }
 
@@ -448,7 +448,7 @@ def run_gnn(args, world, rank, dev):
 
     for i in range(args.warmup):
         step(i)
-    SPMM = ["isic_spmm_csr_f32", "isic_spmm_csr_graphs_f32"]
+    SPMM = ["isic_spmm_csr_f32"]
     elapsed, host_s, loss = timed_region(step, args, world, dev, timer, SPMM, 2 + args.warmup)
     spmm = timer.stop()
     final_loss = float(loss.detach())
@@ -481,9 +481,8 @@ def run_gnn(args, world, rank, dev):
                       "layers": L, "knn_k": k, "parallelism": f"dp{world}",
                       "host_enqueue_ms_per_step": host_s * 1e3 / args.steps, "final_loss": final_loss}
     line["roofline"] = {
-        "bound": "hbm", "kernel": "C-ABI entry isic_spmm_csr_graphs_f32 (GCNConv aggregation of a batch of graphs: neighbour "
-                                  "gather + segmented sum, forward and transposed backward; one graph's node features "
-                                  "staged in LDS per block)",
+        "bound": "hbm", "kernel": "C-ABI entry isic_spmm_csr_f32 (GCNConv aggregation: neighbour gather + segmented sum, "
+                                  "forward and transposed backward)",
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": pmc_traffic("gnn", graphs_per_step=Gs, nodes=N, hidden=F, knn_k=k),
         "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1),

@@ -270,17 +270,6 @@ int isic_gcn_csr_build(const int64_t* src, const int64_t* dst, const float* edge
 int isic_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, const float* bias,
                       float* out, int64_t n_rows, int F, float alpha, const float* addend, float addend_scale,
                       void* stream);
-/* The same aggregation for a BATCH of small graphs (block-diagonal operator): graph g owns the nodes
- * [offsets[g], offsets[g+1]) (device int64, n_graphs + 1 entries) and max_nodes bounds its node count.  One block per
- * graph stages the graph's node features in LDS once (LDS-DMA) and gathers the neighbours from there: HBM and L2 move
- * the compulsory bytes only.  Neighbours outside a graph's range are still handled (read from global memory), graphs
- * larger than max_nodes too (nothing staged); when F or max_nodes does not fit (isic_spmm_csr_graphs_supported == 0) the
- * call is isic_spmm_csr_f32.  Same accumulation order as isic_spmm_csr_f32: bit-identical results. */
-int isic_spmm_csr_graphs_supported(int F, int max_nodes);
-int isic_spmm_csr_graphs_f32(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, const float* bias,
-                             float* out, int64_t n_rows, int F, float alpha, const float* addend, float addend_scale,
-                             const int64_t* offsets, int n_graphs, int max_nodes, void* stream);
-
 /* Graph attention (PyG GATConv(heads=H, concat=True, dropout=p) as called at
  * 05_train_gnns.py:83-86) on the GCN-mode CSR (self loops re-added; `val` unused):
  *   al[n,h] = <x'[n,h,:], att_src[h,:]>, ar[n,h] = <x'[n,h,:], att_dst[h,:]>        (isic_gat_scores)

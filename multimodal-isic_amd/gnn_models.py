@@ -239,8 +239,6 @@ class GraphMIL(nn.Module):
         offs = BagOffsets.single(x.shape[0], x.device) if single else as_offsets(offsets, x.device)
         clk, tr = self.dropout_clock, self.training
         g = self._graph(edge_index, edge_weight, x.shape[0], graph)
-        if g is not None:
-            g.bag_offsets = offs          # graph boundaries: lets the aggregation stage one graph per block in LDS
         x_in = ops.linear(x, self.input_proj.weight, self.input_proj.bias) if self.input_proj is not None else x
         h, x0 = x_in, x_in
         p_drop = self.gnn_dropout.p

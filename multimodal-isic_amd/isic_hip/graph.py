@@ -78,17 +78,10 @@ GraphBatch.from_parts = staticmethod(_graph_from_parts)
 
 
 def _spmm_launch(graph, transposed, x, bias, out, alpha, addend, addend_scale):
-    """One aggregation launch.  A ``GraphBatch`` that knows its graph boundaries (``bag_offsets``: a batch of small graphs,
-    block-diagonal operator -- forward and transposed alike) goes to the graph-resident kernel (``spmm_graph.hip``: a
-    graph's node features staged in LDS once); anything else to the grouped-lane gather."""
+    """One aggregation launch (forward CSR or its transpose)."""
     rp, c, v = (graph.rowptr_t, graph.col_t, graph.val_t) if transposed else (graph.rowptr, graph.col, graph.val)
     n, F = x.shape
-    offs = getattr(graph, "bag_offsets", None)
-    if offs is not None and offs.total == n and call("isic_spmm_csr_graphs_supported", int(F), int(offs.max_bag)):
-        call("isic_spmm_csr_graphs_f32", rp, c, v, x, bias, out, n, F, alpha, addend, addend_scale, offs.device,
-             int(offs.num_bags), int(offs.max_bag))
-    else:
-        call("isic_spmm_csr_f32", rp, c, v, x, bias, out, n, F, alpha, addend, addend_scale)
+    call("isic_spmm_csr_f32", rp, c, v, x, bias, out, n, F, alpha, addend, addend_scale)
 
 
 class SpmmFn(torch.autograd.Function):

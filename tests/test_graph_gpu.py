@@ -339,42 +339,3 @@ def test_heterophily_measures_vs_reference_golden_and_oracle():
         for k in ("H_kl", "H_dirichlet", "H_spatial", "H_compat_matrix", "lambda_2"):
             np.testing.assert_allclose(got[i][k], ref[k], rtol=2e-5, atol=2e-6, err_msg=f"image {i} {k}")
         assert abs(got[i]["H_adj"] - ref["H_adj"]) < 1e-9
-
-
-@pytest.mark.parametrize("F", [32, 64, 128, 200])
-def test_graph_resident_spmm_equals_the_gather_kernel(F):
-    """`isic_spmm_csr_graphs_f32` (spmm_graph.hip: one block per graph, the graph's node features staged in LDS once) is
-    BIT-IDENTICAL to `isic_spmm_csr_f32` (same accumulation order) on a ragged batch of graphs, forward and transposed:
-    graphs of 1 .. 230 nodes, rows with more than LPR edges, isolated nodes, a few edges that leave their graph's node
-    range (served from global memory), with bias + addend (GCN2Conv form) -- also when the caller understates max_nodes
-    (oversized graphs are computed without staging) and at a width whose graphs do not fit LDS (falls back)."""
-    from isic_hip.bags import BagOffsets
-    from isic_hip.graph import GraphBatch
-    from isic_hip.lib import call
-    gen = torch.Generator().manual_seed(31 + F)
-    sizes = [196, 196, 1, 230, 57, 196, 3, 120, 196, 64]
-    offs_h = np.concatenate([[0], np.cumsum(sizes)])
-    n = int(offs_h[-1])
-    eis = []
-    for m, o in zip(sizes, offs_h[:-1]):
-        if m > 1:
-            e = _rand_graph(m, 8 * m, gen)
-            e[1, : min(80, e.shape[1])] = 0                      # node 0 of the graph collects > 64 edges (several LPR chunks)
-            eis.append(e + int(o))
-    stray = torch.stack([torch.randint(0, n, (12,), generator=gen), torch.randint(0, n, (12,), generator=gen)])
-    ei = torch.cat(eis + [stray], dim=1)
-    gb = GraphBatch(ei.to(DEV), n)
-    offs = BagOffsets(offs_h, torch.device(DEV))
-    x = torch.randn(n, F, generator=gen).to(DEV)
-    bias = torch.randn(F, generator=gen).to(DEV)
-    add = torch.randn(n, F, generator=gen).to(DEV)
-    for rp, c, v in ((gb.rowptr, gb.col, gb.val), (gb.rowptr_t, gb.col_t, gb.val_t)):
-        ref = torch.empty_like(x)
-        call("isic_spmm_csr_f32", rp, c, v, x, bias, ref, n, F, 0.7, add, 0.3)
-        for max_nodes in (offs.max_bag, 100):                    # 100: understated -> graphs of 120..230 nodes are not staged
-            got = torch.full_like(x, float("nan"))
-            call("isic_spmm_csr_graphs_f32", rp, c, v, x, bias, got, n, F, 0.7, add, 0.3, offs.device, offs.num_bags, max_nodes)
-            torch.cuda.synchronize()
-            assert torch.equal(got, ref), (F, max_nodes, float((got - ref).abs().max()))
-    assert bool(call("isic_spmm_csr_graphs_supported", 128, 196)) and not bool(call("isic_spmm_csr_graphs_supported", 256, 196))
-    assert not bool(call("isic_spmm_csr_graphs_supported", 130, 196))
