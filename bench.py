@@ -117,8 +117,9 @@ class KernelTimer:
                 e0.record()
                 rc = orig(name, *args, stream=stream)
                 e1.record()
-                # scalars only: keeping the tensor arguments would pin every activation of the timed region
-                timer.records.append((name, tuple(None if isinstance(a, torch.Tensor) else a for a in args), e0, e1))
+                # scalars only (a tensor argument is recorded as True, a NULL pointer as None): keeping the tensors would
+                # pin every activation of the timed region
+                timer.records.append((name, tuple(True if isinstance(a, torch.Tensor) else a for a in args), e0, e1))
                 return rc
             return orig(name, *args, stream=stream)
 
@@ -329,8 +330,12 @@ def run_vit(args, world, rank, dev):
     if rank != 0:
         return None
     ms = sum(m for _n, _a, m in gemm)
-    fl = sum(2.0 * a[5] * a[6] * a[7] for _n, a, _m in gemm)          # (A, W, bias, residual, C, M, N, K, ...)
+    fl = sum(2.0 * a[5] * a[6] * a[7] for _n, a, _m in gemm)          # (A, W, bias, residual, C, M, N, K, act, residual_rows)
+    # algorithmic bytes of a launch: A[M,K] + W[N,K] + C[M,N] (+ the residual: [M,N], or [residual_rows,N] broadcast) in fp16
+    by = sum(2.0 * (a[5] * a[7] + a[6] * a[7] + a[5] * a[6] + (0 if a[3] is None else (a[9] if a[9] > 0 else a[5]) * a[6]))
+             for _n, a, _m in gemm)
     achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     line = base_line("images/sec (ViT-S/16 fp16 patch-encoder forward) @ 224x224", "images/s",
                      world * n_img * args.steps / elapsed, world, args, elapsed, "f16")
     line["scaling"] = "weak"
@@ -338,13 +343,20 @@ def run_vit(args, world, rank, dev):
                       "dim": enc.dim, "depth": enc.depth, "heads": enc.heads, "parallelism": f"replicas{world}",
                       "host_enqueue_ms_per_step": host_s * 1e3 / args.steps,
                       "whole_forward_algorithmic_tflops": enc.flops_per_image() * n_img * args.steps / elapsed / 1e12}
+    # Which roofline binds these GEMMs?  Their arithmetic intensity is 2MNK / 2(MK + NK + MN [+ MN]) = 130-310 FLOP per
+    # algorithmic byte at N, K in {384, 1152, 1536} -- below the machine balance of 2.5 PFLOP/s / 8 TB/s = 312 (403 against
+    # the 6.2 TB/s a copy reaches): every one of them is HBM-bound by its own operands, so `bound` is "hbm" and the MFMA
+    # figure is reported next to it.
     line["roofline"] = {
-        "bound": "mfma", "kernel": "C-ABI entry isic_gemm_f16 (every Linear of the encoder with its bias / GELU / residual "
-                                   "epilogue: 49 launches per forward)",
-        "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
+        "bound": "hbm", "kernel": "C-ABI entry isic_gemm_f16 (every Linear of the encoder with its bias / GELU / residual "
+                                  "epilogue: 49 launches per forward; arithmetic intensity 130-310 FLOP per algorithmic "
+                                  "byte < the machine balance 312)",
+        "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
         "traffic": pmc_traffic("vit", images_per_step=n_img, image_size=S),
         "launches": len(gemm), "avg_launch_ms": ms / max(len(gemm), 1),
+        "algorithmic_bytes_per_launch": by / max(len(gemm), 1),
         "algorithmic_gflop_per_launch": fl / max(len(gemm), 1) / 1e9, "share_of_step_time": ms * 1e-3 / elapsed,
+        "mfma": {"achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS},
         "measured": "HIP events inside the timed region",
     }
     line["kernel_time"] = split

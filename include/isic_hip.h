@@ -147,6 +147,14 @@ int isic_layernorm_bwd_clk(const float* dy, const float* x, const float* gamma, 
                            uint32_t drop_threshold, float drop_scale, uint64_t seed, uint64_t stream_id,
                            const uint64_t* clock, void* stream);
 
+/* ... with a workspace (isic_layernorm_bwd_workspace_bytes(N) bytes; may be NULL / 0): the blocks' dgamma / dbeta partial
+ * rows are then added in block order instead of through fp32 atomics -- bit-reproducible. */
+size_t isic_layernorm_bwd_workspace_bytes(int N);
+int isic_layernorm_bwd_ws(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
+                          const float* rstd, float* dx, float* dgamma, float* dbeta, int M, int N, int relu,
+                          uint32_t drop_threshold, float drop_scale, uint64_t seed, uint64_t stream_id,
+                          const uint64_t* clock, void* workspace, size_t workspace_bytes, void* stream);
+
 /* y = x / max(||x||_2, eps) per row and its backward: F.normalize of
  * SAGEConv(normalize=True) (05_train_gnns.py:87-88). */
 int isic_l2normalize_fwd(const float* x, float* y, float* norm, int M, int N, float eps, void* stream);

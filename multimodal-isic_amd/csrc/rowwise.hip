@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const float* __restrict__ beta, const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
     float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int N, int relu,
     unsigned int thr, float scale, unsigned long long seed, unsigned long long stream_id,
-    const unsigned long long* __restrict__ clock) {
+    const unsigned long long* __restrict__ clock, float* __restrict__ partial) {
   if (clock) stream_id += clock[0] * 1024ULL;        // device step clock (captured graphs): stream = base + step * 1024
   __shared__ float red[2][4][64 * JN];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -93,8 +93,28 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
   for (int col = threadIdx.x; col < N; col += 256) {
     const float tg = (red[0][0][col] + red[0][1][col]) + (red[0][2][col] + red[0][3][col]);
     const float tb = (red[1][0][col] + red[1][1][col]) + (red[1][2][col] + red[1][3][col]);
-    atomicAdd(&dgamma[col], tg);
-    atomicAdd(&dbeta[col], tb);
+    if (partial) {                                   // deterministic: the block's own row, ln_bwd_reduce_kernel adds in order
+      partial[(size_t)blockIdx.x * 2 * N + col] = tg;
+      partial[(size_t)blockIdx.x * 2 * N + N + col] = tb;
+    } else {
+      atomicAdd(&dgamma[col], tg);
+      atomicAdd(&dbeta[col], tb);
+    }
+  }
+}
+
+// dgamma[n] += sum over the blocks' partial rows (and dbeta likewise), in block order: 16 lanes per column, fixed xor tree
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int N,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int g = threadIdx.x & 15;
+  const int n = blockIdx.x * 16 + (threadIdx.x >> 4);        // 0 .. 2N-1: dgamma columns, then dbeta columns
+  float s = 0.f;
+  if (n < 2 * N)
+    for (int b = g; b < nblocks; b += 16) s += partial[(size_t)b * 2 * N + n];
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+  if (n < 2 * N && g == 0) {
+    if (n < N) dgamma[n] += s; else dbeta[n - N] += s;
   }
 }
 
@@ -160,7 +180,7 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_vec_kernel(
     const float* __restrict__ beta, const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
     float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int relu,
     unsigned int thr, float scale, unsigned long long seed, unsigned long long stream_id,
-    const unsigned long long* __restrict__ clock) {
+    const unsigned long long* __restrict__ clock, float* __restrict__ partial) {
   if (clock) stream_id += clock[0] * 1024ULL;        // device step clock (captured graphs): stream = base + step * 1024
   constexpr int RPW = 64 / LPR, N = 4 * LPR;
   __shared__ f32x4 red[2][1024];
@@ -203,10 +223,15 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_vec_kernel(
     f32x4 tg = {0.f, 0.f, 0.f, 0.f}, tb = tg;
 #pragma unroll
     for (int k = 0; k < 16 * RPW; ++k) { tg += red[0][k * LPR + threadIdx.x]; tb += red[1][k * LPR + threadIdx.x]; }
+    if (partial) {                                   // deterministic: the block's own row of [2][N]
+      *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.x * 2 * N + threadIdx.x * 4) = tg;
+      *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.x * 2 * N + N + threadIdx.x * 4) = tb;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      atomicAdd(&dgamma[threadIdx.x * 4 + e], tg[e]);
-      atomicAdd(&dbeta[threadIdx.x * 4 + e], tb[e]);
+      for (int e = 0; e < 4; ++e) {
+        atomicAdd(&dgamma[threadIdx.x * 4 + e], tg[e]);
+        atomicAdd(&dbeta[threadIdx.x * 4 + e], tb[e]);
+      }
     }
   }
 }
@@ -383,10 +408,26 @@ int isic_layernorm_bwd_clk(const float* dy, const float* x, const float* gamma, 
                            const float* rstd, float* dx, float* dgamma, float* dbeta, int M, int N, int relu,
                            uint32_t drop_threshold, float drop_scale, uint64_t seed, uint64_t stream_id,
                            const uint64_t* clock, void* stream) {
+  return isic_layernorm_bwd_ws(dy, x, gamma, beta, mean, rstd, dx, dgamma, dbeta, M, N, relu, drop_threshold, drop_scale, seed,
+                               stream_id, clock, nullptr, 0, stream);
+}
+
+size_t isic_layernorm_bwd_workspace_bytes(int N) {
+  return N > 0 && N <= 1024 ? (size_t)1024 * 2 * N * sizeof(float) : 0;      // at most 1024 blocks, a [2][N] row each
+}
+
+int isic_layernorm_bwd_ws(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
+                          const float* rstd, float* dx, float* dgamma, float* dbeta, int M, int N, int relu,
+                          uint32_t drop_threshold, float drop_scale, uint64_t seed, uint64_t stream_id,
+                          const uint64_t* clock, void* workspace, size_t workspace_bytes, void* stream) {
   ISIC_CHECK_ARG(M >= 0 && N > 0);
   if (M == 0) return ISIC_OK;
   ISIC_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && dgamma && dbeta);
   if (N > 1024) return ISIC_ERR_UNSUPPORTED;
+  // with a workspace the blocks' dgamma / dbeta partial rows are added in block order (bit-reproducible); without one
+  // they meet through fp32 atomics in arrival order
+  float* partial = (workspace && workspace_bytes >= isic_layernorm_bwd_workspace_bytes(N) &&
+                    (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) ? reinterpret_cast<float*>(workspace) : nullptr;
   const bool al16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) |
                       reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0;
   if (al16 && (N == 64 || N == 128 || N == 256)) {
@@ -396,9 +437,12 @@ int isic_layernorm_bwd_clk(const float* dy, const float* x, const float* gamma, 
 #define LAUNCH_LNB(LPR)                                                                                             \
   hipLaunchKernelGGL(layernorm_bwd_vec_kernel<LPR>, dim3(gridv), dim3(1024), 0, as_stream(stream), dy, x, gamma, beta, mean, \
                      rstd, dx, dgamma, dbeta, M, relu, drop_threshold, drop_scale, (unsigned long long)seed,        \
-                     (unsigned long long)stream_id, (const unsigned long long*)clock)
+                     (unsigned long long)stream_id, (const unsigned long long*)clock, partial)
     if (N == 64) LAUNCH_LNB(16); else if (N == 128) LAUNCH_LNB(32); else LAUNCH_LNB(64);
 #undef LAUNCH_LNB
+    if (partial)
+      hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(2 * N, 16)), dim3(256), 0, as_stream(stream), partial, gridv, N,
+                         dgamma, dbeta);
     return isic_launch_status();
   }
   int grid = ceil_div(M, 4 * 8);  // >= 8 rows per wave amortise the atomics
@@ -407,12 +451,15 @@ int isic_layernorm_bwd_clk(const float* dy, const float* x, const float* gamma, 
 #define LAUNCH_LN(JN)                                                                                          \
   hipLaunchKernelGGL(layernorm_bwd_kernel<JN>, dim3(grid), dim3(256), 0, as_stream(stream), dy, x, gamma, beta, \
                      mean, rstd, dx, dgamma, dbeta, M, N, relu, drop_threshold, drop_scale,                     \
-                     (unsigned long long)seed, (unsigned long long)stream_id, (const unsigned long long*)clock)
+                     (unsigned long long)seed, (unsigned long long)stream_id, (const unsigned long long*)clock, partial)
   if (N <= 128) LAUNCH_LN(2);
   else if (N <= 256) LAUNCH_LN(4);
   else if (N <= 512) LAUNCH_LN(8);
   else LAUNCH_LN(16);
 #undef LAUNCH_LN
+  if (partial)
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(2 * N, 16)), dim3(256), 0, as_stream(stream), partial, grid, N,
+                       dgamma, dbeta);
   return isic_launch_status();
 }
 

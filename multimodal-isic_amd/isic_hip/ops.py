@@ -334,8 +334,9 @@ class LayerNormFn(torch.autograd.Function):
         fused = tg is not None and tb is not None      # the kernel ACCUMULATES (+=) into dgamma / dbeta
         dg = tg if fused else torch.zeros((N,), device=x2.device, dtype=torch.float32)
         db = tb if fused else torch.zeros((N,), device=x2.device, dtype=torch.float32)
-        call("isic_layernorm_bwd_clk", dy2, x2, g, b, mean, rstd, dx, dg, db, M, N, relu, drop.threshold, drop.scale,
-             drop.seed, drop.stream, drop.clock)
+        ws = _workspace(call("isic_layernorm_bwd_workspace_bytes", N), x2.device)
+        call("isic_layernorm_bwd_ws", dy2, x2, g, b, mean, rstd, dx, dg, db, M, N, relu, drop.threshold, drop.scale,
+             drop.seed, drop.stream, drop.clock, ws, ws.numel() if ws is not None else 0)
         return dx.reshape(ctx.xshape), (None if fused else dg), (None if fused else db), (dy if ctx.has_res else None), None, None, None
 
 

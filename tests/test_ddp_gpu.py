@@ -154,7 +154,7 @@ def test_bare_multi_gpu_launch_starts_its_own_ranks():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["value"] > 0
     assert line["gnn"]["n_gpus"] == 2 and line["gnn"]["value"] > 0 and line["gnn"]["roofline"]["bound"] == "hbm"
-    assert line["vit"]["n_gpus"] == 2 and line["vit"]["value"] > 0 and line["vit"]["roofline"]["bound"] == "mfma"
+    assert line["vit"]["n_gpus"] == 2 and line["vit"]["value"] > 0 and line["vit"]["roofline"]["bound"] == "hbm"
 
 
 _RCCL_CHILD = r"""
