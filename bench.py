@@ -39,6 +39,7 @@ import torch
 import torch.distributed as dist
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3     # fp32 matrix core (v_mfma_f32_16x16x4_f32), same guide
 HBM_PEAK_GBS = 8000.0            # HBM3E spec, same guide (6.3 TB/s measured streaming)
 WORKLOAD_MIL = ("ISIC-shaped attention-MIL: 256 bags x 64x224x224 patches + 128-d radiomics, "
                 "ResNet-18 encoder, bf16 (BASELINE.json configs[1])")
@@ -460,7 +461,7 @@ def run_gnn(args, world, rank, dev):
 
     for i in range(args.warmup):
         step(i)
-    SPMM = ["isic_spmm_csr_f32"]
+    SPMM = ["isic_spmm_csr_f32", "isic_gemm_f32_ws"]      # the roofline entry + the fp32 GEMMs (second-largest class)
     elapsed, host_s, loss = timed_region(step, args, world, dev, timer, SPMM, 2 + args.warmup)
     spmm = timer.stop()
     final_loss = float(loss.detach())
@@ -483,6 +484,10 @@ def run_gnn(args, world, rank, dev):
     # col + val + rowptr; E counts the self loops GCNConv adds
     E = N * k + N
     per_graph = 2 * N * F * 4 + 2 * E * 4 + (N + 1) * 4
+    gemms = [(a, m) for n_, a, m in spmm if n_ == "isic_gemm_f32_ws"]
+    spmm = [r for r in spmm if r[0] == "isic_spmm_csr_f32"]
+    gemm_ms = sum(m for _a, m in gemms)
+    gemm_fl = sum(2.0 * a[2] * a[3] * a[4] for a, _m in gemms)          # (transA, transB, M, N, K, ...)
     ms = sum(m for _n, _a, m in spmm)
     n_launch = len(spmm)
     achieved = Gs * per_graph * n_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -500,6 +505,11 @@ def run_gnn(args, world, rank, dev):
         "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1),
         "algorithmic_bytes_per_launch": Gs * per_graph, "compulsory_bytes_per_layer_per_graph": per_graph,
         "share_of_step_time": ms * 1e-3 / elapsed, "measured": measured,
+        # the step's largest kernel class next to it: every exact-fp32 GEMM launch of the step (v_mfma_f32_16x16x4_f32)
+        "gemm_f32": {"bound": "mfma", "achieved": gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
+                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": (gemm_fl / (gemm_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS) if gemm_ms > 0 else 0.0,
+                     "launches": len(gemms), "ms_per_step": gemm_ms / max(args.steps, 1)},
     }
     line["kernel_time"] = split
     line["config"]["step_launch"] = "hipGraph replay (device step clock)" if captured is not None else "eager"
