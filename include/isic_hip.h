@@ -271,6 +271,14 @@ size_t isic_gcn_csr_workspace_bytes(int64_t n_nodes, int64_t E);
 int isic_gcn_csr_build(const int64_t* src, const int64_t* dst, const float* edge_weight, int64_t E, int64_t n_nodes,
                        int mode, int32_t* rowptr, int32_t* col, float* val, int32_t* rowptr_t, int32_t* col_t,
                        float* val_t, int32_t* perm_t, void* workspace, size_t workspace_bytes, void* stream);
+/* A step's batched CSR (+ transpose) out of per-graph pieces built once: graphs sel[0..B) of a set in which every graph
+ * has n nodes and nnz stored entries; inputs are [G, n] row pointers and [G, nnz] columns / values / perm_t with LOCAL ids
+ * (row pointers relative to the graph's first entry), outputs the batch's arrays with global ids (rowptr: B*n + 1 entries).
+ * One launch per optimizer step instead of re-uploading every graph (05_train_gnns.py:340-343). */
+int isic_csr_batch_assemble(const int64_t* sel, int B, int n, int nnz, const int32_t* rowptr, const int32_t* rowptr_t,
+                            const int32_t* col, const int32_t* col_t, const float* val, const float* val_t,
+                            const int32_t* perm_t, int32_t* rowptr_out, int32_t* rowptr_t_out, int32_t* col_out,
+                            int32_t* col_t_out, float* val_out, float* val_t_out, int32_t* perm_t_out, void* stream);
 /* out[i,:] = alpha * sum_{e in row i} val[e] * x[col[e],:] (+ bias) (+ addend_scale*addend[i,:])
  * -- the neighbour gather / segmented sum of GCNConv.propagate
  * (05_train_gnns.py:184-185); GCN2Conv's (1-alpha) A^ x + alpha x_0 with addend.

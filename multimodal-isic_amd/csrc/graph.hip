@@ -358,6 +358,40 @@ inline int grid_for(int64_t n, int block, int cap = 4096) {
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+
+// One launch assembles a step's batched CSR (and its transpose) out of per-graph CSR pieces built once
+// (train.GraphStore): B graphs picked by `sel`, every graph with n nodes and nnz stored entries, local ids.
+//   rowptr_out[b*n + r] = rowptr[g*n + r] + b*nnz (+ the closing entry B*nnz),  col_out[b*nnz + e] = col[g*nnz + e] + b*n,
+//   perm_out[b*nnz + e] = perm[g*nnz + e] + b*nnz,  val copied;  g = sel[b].
+// Replaces seven index_selects, five integer adds, two concatenations and their helper kernels per optimizer step
+// (05_train_gnns.py:340-343 re-uploads x and edge_index of every graph at every step instead).
+__global__ __launch_bounds__(256) void csr_batch_assemble_kernel(
+    const int64_t* __restrict__ sel, int B, int n, int nnz, const int* __restrict__ rowptr, const int* __restrict__ rowptr_t,
+    const int* __restrict__ col, const int* __restrict__ col_t, const float* __restrict__ val, const float* __restrict__ val_t,
+    const int* __restrict__ perm_t, int* __restrict__ rowptr_o, int* __restrict__ rowptr_t_o, int* __restrict__ col_o,
+    int* __restrict__ col_t_o, float* __restrict__ val_o, float* __restrict__ val_t_o, int* __restrict__ perm_t_o) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t ne = (int64_t)B * nnz, nr = (int64_t)B * n;
+  if (i < ne) {
+    const int b = (int)(i / nnz), e = (int)(i - (int64_t)b * nnz);
+    const int64_t src = sel[b] * nnz + e;
+    col_o[i] = col[src] + b * n;
+    col_t_o[i] = col_t[src] + b * n;
+    val_o[i] = val[src];
+    val_t_o[i] = val_t[src];
+    perm_t_o[i] = perm_t[src] + b * nnz;
+  }
+  if (i < nr) {
+    const int b = (int)(i / n), r = (int)(i - (int64_t)b * n);
+    const int64_t src = sel[b] * n + r;
+    rowptr_o[i] = rowptr[src] + b * nnz;
+    rowptr_t_o[i] = rowptr_t[src] + b * nnz;
+  } else if (i == nr) {
+    rowptr_o[i] = (int)ne;
+    rowptr_t_o[i] = (int)ne;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -450,6 +484,23 @@ int isic_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* va
     hipLaunchKernelGGL(spmm_kernel<2>, grid, dim3(256), 0, s, rowptr, col, val, x, bias, out, n_rows, F, alpha, addend, addend_scale);
   else
     hipLaunchKernelGGL(spmm_kernel<1>, grid, dim3(256), 0, s, rowptr, col, val, x, bias, out, n_rows, F, alpha, addend, addend_scale);
+  return isic_launch_status();
+}
+
+int isic_csr_batch_assemble(const int64_t* sel, int B, int n, int nnz, const int32_t* rowptr, const int32_t* rowptr_t,
+                            const int32_t* col, const int32_t* col_t, const float* val, const float* val_t,
+                            const int32_t* perm_t, int32_t* rowptr_out, int32_t* rowptr_t_out, int32_t* col_out,
+                            int32_t* col_t_out, float* val_out, float* val_t_out, int32_t* perm_t_out, void* stream) {
+  ISIC_CHECK_ARG(B >= 0 && n > 0 && nnz >= 0);
+  if (B == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(sel && rowptr && rowptr_t && col && col_t && val && val_t && perm_t && rowptr_out && rowptr_t_out && col_out &&
+                 col_t_out && val_out && val_t_out && perm_t_out);
+  ISIC_CHECK_ARG((int64_t)B * nnz < 0x7FFFFFFFLL && (int64_t)B * n < 0x7FFFFFFFLL);
+  const int64_t ne = (int64_t)B * nnz, nr = (int64_t)B * n + 1;
+  const int64_t work = ne > nr ? ne : nr;
+  hipLaunchKernelGGL(csr_batch_assemble_kernel, dim3((unsigned)ceil_div64(work, 256)), dim3(256), 0, as_stream(stream), sel, B, n,
+                     nnz, rowptr, rowptr_t, col, col_t, val, val_t, perm_t, rowptr_out, rowptr_t_out, col_out, col_t_out,
+                     val_out, val_t_out, perm_t_out);
   return isic_launch_status();
 }
 

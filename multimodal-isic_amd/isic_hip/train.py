@@ -22,6 +22,7 @@ import torch.distributed as dist
 from . import ddp, ops, optim
 from .bags import BagOffsets
 from .graph import GraphBatch
+from .lib import call
 
 
 def dist_info():
@@ -349,17 +350,16 @@ class GraphStore:
         """``sel``: device int64 tensor of graph indices."""
         st = self._stack
         n, nnz, B = st["n"], st["nnz"], int(sel.numel())
-        i32 = torch.int32
-        noff = (torch.arange(B, device=self.device, dtype=i32) * n).view(B, 1)
-        eoff = (torch.arange(B, device=self.device, dtype=i32) * nnz).view(B, 1)
-        tail = torch.full((1,), B * nnz, device=self.device, dtype=i32)
-        parts = {
-            "rowptr": torch.cat([(st["rowptr"][sel] + eoff).reshape(-1), tail]),
-            "rowptr_t": torch.cat([(st["rowptr_t"][sel] + eoff).reshape(-1), tail]),
-            "col": (st["col"][sel] + noff).reshape(-1), "col_t": (st["col_t"][sel] + noff).reshape(-1),
-            "val": st["val"][sel].reshape(-1), "val_t": st["val_t"][sel].reshape(-1),
-            "perm_t": (st["perm_t"][sel] + eoff).reshape(-1),
-        }
+        i32, dev = torch.int32, self.device
+        parts = {"rowptr": torch.empty(B * n + 1, device=dev, dtype=i32), "rowptr_t": torch.empty(B * n + 1, device=dev, dtype=i32),
+                 "col": torch.empty(B * nnz, device=dev, dtype=i32), "col_t": torch.empty(B * nnz, device=dev, dtype=i32),
+                 "val": torch.empty(B * nnz, device=dev, dtype=torch.float32),
+                 "val_t": torch.empty(B * nnz, device=dev, dtype=torch.float32),
+                 "perm_t": torch.empty(B * nnz, device=dev, dtype=i32)}
+        # ONE launch (graph.hip: csr_batch_assemble_kernel) instead of seven index_selects + offset adds + concatenations
+        call("isic_csr_batch_assemble", sel, B, n, nnz, st["rowptr"], st["rowptr_t"], st["col"], st["col_t"], st["val"],
+             st["val_t"], st["perm_t"], parts["rowptr"], parts["rowptr_t"], parts["col"], parts["col_t"], parts["val"],
+             parts["val_t"], parts["perm_t"])
         return GraphBatch.from_parts(B * n, B * (nnz - (n if self.mode == "gcn" else 0)), self.mode, parts)
 
     def batch(self, idx, cache=False):
