@@ -268,3 +268,33 @@ def test_committed_pmc_traffic_profile_matches_the_kernels():
     assert bench.pmc_traffic("mil", bags_per_step=32, patches=64, image_size=224) > 0
     assert bench.pmc_traffic("gnn", graphs_per_step=256, nodes=196, hidden=128, knn_k=8) > 0
     assert bench.pmc_traffic("vit", images_per_step=2048, image_size=224) > 0
+
+
+def test_torch_library_ops_are_registered_with_fake_implementations():
+    """isic_hip/torch_ops.py registers torch.ops.isic_hip.*: schemas exist, none claims to mutate or alias, and the fake
+    (meta) implementations give the shapes / dtypes the kernels produce -- checked without a GPU under FakeTensorMode
+    (the real launches are compared in tests/test_torch_ops_gpu.py)."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from isic_hip import torch_ops  # noqa: F401
+    O = torch.ops.isic_hip
+    for name in ("linear", "linear_backward", "layer_norm", "layer_norm_backward", "spmm", "spmm_backward", "attn_pool",
+                 "attn_pool_backward", "softmax_rows", "softmax_rows_backward", "cross_entropy", "gemm_f32"):
+        schema = getattr(O, name).default._schema
+        assert not schema.is_mutable, name
+        assert all(a.alias_info is None for a in list(schema.arguments) + list(schema.returns)), name
+    with FakeTensorMode():
+        x, w, b = torch.empty(10, 32), torch.empty(8, 32), torch.empty(8)
+        assert O.linear(x, w, b, 1, 0, 1.0, 0, 0).shape == (10, 8)
+        dx, dw, db = O.linear_backward(torch.empty(10, 8), x, w, torch.empty(10, 8), 1, 1.0, True, True, False)
+        assert dx.shape == x.shape and dw.shape == w.shape and db.numel() == 0
+        y, mean, rstd = O.layer_norm(x, torch.empty(32), torch.empty(32), None, 1e-5, True, 0, 1.0, 0, 0)
+        assert y.shape == x.shape and mean.shape == (10,) and rstd.shape == (10,)
+        rp, c, v = torch.empty(11, dtype=torch.int32), torch.empty(40, dtype=torch.int32), torch.empty(40)
+        assert O.spmm(rp, c, v, rp, c, v, x, None, 1.0).shape == x.shape
+        z, att, t = O.attn_pool(torch.empty(50, 16), torch.empty(24, 16), torch.empty(24), torch.empty(3, 8), torch.empty(3),
+                                torch.empty(6, dtype=torch.int64), 16, 3)
+        assert z.shape == (5, 16) and att.shape == (50, 3) and t.shape == (50, 24)
+        loss, d = O.cross_entropy(torch.empty(5, 4), torch.empty(5, dtype=torch.int64), 0)
+        assert loss.shape == () and d.shape == (5, 4)
+        assert O.gemm_f32(torch.empty(32, 10), torch.empty(8, 32), True, True, None, 0).shape == (10, 8)
+    assert torch_ops.drop_args(None) == (0, 1.0, 0, 0)

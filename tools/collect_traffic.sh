@@ -63,7 +63,7 @@ for s in "$SECTIONS".split():
     res[s] = {"kernel_source_hash": bench.kernel_source_hash(bench.TRAFFIC_SOURCES[s]), "workload": workload,
               "hbm_bytes_per_launch": (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / launches,
               "fetch_kib_total": tot["FETCH_SIZE"], "write_kib_total": tot["WRITE_SIZE"], "dispatches": disp["FETCH_SIZE"],
-              "launches": launches, "steps_profiled": steps["FETCH_SIZE"],
+              "launches": launches, "steps_profiled": steps["FETCH_SIZE"] if marker else None,
               "note": "FETCH_SIZE doubled (gfx950 wide-read correction); separate --pmc passes per counter"}
 json.dump(res, open(path, "w"), indent=1, sort_keys=True)
 os.makedirs("$OUT", exist_ok=True)
