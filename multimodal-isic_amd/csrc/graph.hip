@@ -268,60 +268,40 @@ __global__ __launch_bounds__(256) void spmm_kernel(const int* __restrict__ rowpt
   }
 }
 
-// F <= 256, F % 4 == 0: a GROUP of LPR lanes (16 bytes of the row each) owns an output row, 64 / LPR rows per wave.
+// F <= 256, F % 4 == 0: a GROUP of LPR lanes (16 bytes of the row each) accumulates one run of edges; a block of 256 / LPR
+// groups owns as many consecutive output rows.
 // The one-wave-per-row kernel above walks its ~9 edges through two dependent loads each (column index, then the
-// neighbour row) with nothing else in flight: latency-bound at a tenth of the HBM rate.  Here the group fetches the
+// neighbour row) with nothing else in flight: latency-bound at a tenth of the HBM rate.  Here a group fetches the
 // indices and weights of up to LPR edges with ONE coalesced load, broadcasts them by lane shuffles, and keeps four
-// independent neighbour-row loads in flight.  Accumulation order per row is unchanged (edge order): same results.
-constexpr int SPMM_THREADS = 256, UNR = 4;     // (12 in flight measured slower: 0.25 vs 0.21 ms forward)
+// independent neighbour-row loads in flight.
+// Round 3: HUB ROWS ARE SPLIT.  In a k-NN graph every row of one orientation has k + 1 entries, but the other
+// orientation's rows are in-degrees -- 1 to 135 at k = 8 on 196 high-dimensional points (hubness), 5 % of the rows
+// >= 32 -- and a launch was as long as its longest row's chain of dependent gathers (30 us against 16 us for the uniform
+// orientation on the same bytes).  A block without a row of more than SPMM_SHORT entries works as before (one row per
+// group).  Otherwise the block's rows are cut into ITEMS of <= `ch` (8, doubled until the block has <= MAXI items)
+// consecutive entries, dealt round-robin to the groups; a row of one item is finished by its group, the partial sums of a
+// split row go through LDS and are added IN ITEM ORDER by the row's own group: the result depends on the lengths of the
+// block's rows only, never on timing (bit-reproducible), and a 135-entry row costs three rounds of two gathers.
+constexpr int SPMM_THREADS = 256, UNR = 4;     // (12 gathers in flight measured slower: 0.25 vs 0.21 ms forward)
+constexpr int SPMM_SHORT = 16, SPMM_CH_LOG2 = 3;
 template <int LPR>
 __global__ __launch_bounds__(SPMM_THREADS) void spmm_group_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                           const float* __restrict__ val, const float* __restrict__ x,
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           int64_t n_rows, int F, float alpha,
                                                           const float* __restrict__ addend, float addend_scale) {
-  constexpr int RW = 64 / LPR;
+  constexpr int G = SPMM_THREADS / LPR;                    // groups = rows per block
+  constexpr int MAXI = LPR == 64 ? 16 : 32;                // items per block whose partial sums fit the LDS slots
+  __shared__ float4 part[MAXI][LPR];
   const int lane = threadIdx.x & 63, gl = lane & (LPR - 1), g0 = lane - gl;      // lane in group, first lane of the group
+  const int grp = threadIdx.x / LPR;
   const int64_t per_xcd = (gridDim.x + 7) / 8;
   const int64_t chunk = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);      // may exceed the last chunk: rows >= n_rows
-  const int64_t row = (chunk * (SPMM_THREADS / 64) + (threadIdx.x >> 6)) * RW + (lane / LPR);
-  const bool row_ok = row < n_rows;
-  const int b = row_ok ? rowptr[row] : 0, deg = row_ok ? rowptr[row + 1] - b : 0;
+  const int64_t row0 = chunk * G;
   const bool fl = gl * 4 < F;                                                     // this lane holds features 4gl .. 4gl+3
   const float* xl = x + gl * 4;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int base = 0;; base += LPR) {
-    const int cnt = min(LPR, deg - base);                  // edges of this group's row in this chunk (<= 0: none left)
-    int maxcnt = cnt;                                      // wave-uniform trip count: the largest chunk of the wave's rows
-#pragma unroll
-    for (int o = LPR; o < 64; o <<= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, o, 64));
-    if (maxcnt <= 0) break;
-    int c = 0;
-    float w = 0.f;
-    if (gl < cnt) { c = col[b + base + gl]; w = val[b + base + gl]; }
-    for (int j = 0; j < maxcnt; j += UNR) {
-      int cj[UNR];
-      float wj[UNR];
-      float4 xv[UNR];
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int src = g0 + ((j + u) & (LPR - 1));
-        cj[u] = __shfl(c, src, 64);
-        wj[u] = __shfl(w, src, 64);
-      }
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j + u < cnt && fl) xv[u] = *reinterpret_cast<const float4*>(xl + (int64_t)cj[u] * F);
-      }
-#pragma unroll
-      for (int u = 0; u < UNR; ++u)
-        if (j + u < cnt) {
-          acc.x += wj[u] * xv[u].x; acc.y += wj[u] * xv[u].y; acc.z += wj[u] * xv[u].z; acc.w += wj[u] * xv[u].w;
-        }
-    }
-  }
-  if (row_ok && fl) {
+  auto finish = [&](int64_t row, float4 acc) {
+    if (!fl) return;
     float4 o = make_float4(alpha * acc.x, alpha * acc.y, alpha * acc.z, alpha * acc.w);
     if (bias) {
       const float4 bv = *reinterpret_cast<const float4*>(bias + gl * 4);
@@ -332,6 +312,101 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_group_kernel(const int* __r
       o.x += addend_scale * av.x; o.y += addend_scale * av.y; o.z += addend_scale * av.z; o.w += addend_scale * av.w;
     }
     *reinterpret_cast<float4*>(out + row * F + gl * 4) = o;
+  };
+  // sum of w * x[col] over the `deg` stored entries from slot b on, in slot order
+  auto gather = [&](int b, int deg) -> float4 {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = 0;; base += LPR) {
+      const int cnt = min(LPR, deg - base);                // entries of this group's run in this chunk (<= 0: none left)
+      int maxcnt = cnt;                                    // wave-uniform trip count: the largest chunk of the wave's groups
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, o, 64));
+      if (maxcnt <= 0) break;
+      int c = 0;
+      float w = 0.f;
+      if (gl < cnt) { c = col[b + base + gl]; w = val[b + base + gl]; }
+      for (int j = 0; j < maxcnt; j += UNR) {
+        int cj[UNR];
+        float wj[UNR];
+        float4 xv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int src = g0 + ((j + u) & (LPR - 1));
+          cj[u] = __shfl(c, src, 64);
+          wj[u] = __shfl(w, src, 64);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (j + u < cnt && fl) xv[u] = *reinterpret_cast<const float4*>(xl + (int64_t)cj[u] * F);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+          if (j + u < cnt) {
+            acc.x += wj[u] * xv[u].x; acc.y += wj[u] * xv[u].y; acc.z += wj[u] * xv[u].z; acc.w += wj[u] * xv[u].w;
+          }
+      }
+    }
+    return acc;
+  };
+
+  // the group's own row (rounds 1-2: the whole kernel) ...
+  const int64_t row = row0 + grp;
+  const bool row_ok = row < n_rows;
+  const int b_own = row_ok ? rowptr[row] : 0, deg_own = row_ok ? rowptr[row + 1] - b_own : 0;
+  // ... and the block's rows in the lanes of every wave (lane i < G: row i; all waves hold the same table)
+  int rp_l = 0;
+  if (lane <= G) {
+    const int64_t r = row0 + lane;
+    rp_l = rowptr[r < n_rows ? r : n_rows];
+  }
+  const int d_l = __shfl_down(rp_l, 1, 64) - rp_l;         // row length (lanes < G)
+  const bool valid_l = lane < G && row0 + lane < n_rows;
+  if (__ballot(valid_l && d_l > SPMM_SHORT) == 0) {        // block-uniform: no long row, one row per group
+    const float4 acc = gather(b_own, deg_own);
+    if (row_ok) finish(row, acc);
+    return;
+  }
+  // item table: items of the row, exclusive prefix of the items; looked up by lane shuffles
+  int sh = SPMM_CH_LOG2, it_l, incl, total;                // item length ch = 1 << sh = 8, 16, ...
+  for (;;) {                                               // block-uniform
+    it_l = valid_l ? max(1, (d_l + (1 << sh) - 1) >> sh) : 0;       // an empty row still has an item: its output is written
+    incl = it_l;
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      incl += lane >= o ? up : 0;
+    }
+    total = __builtin_amdgcn_readlane(incl, G - 1);
+    if (total <= MAXI) break;
+    ++sh;
+  }
+  const int ofs_l = incl - it_l;
+  const int ch = 1 << sh;
+  for (int t0 = 0; t0 < total; t0 += G) {                  // block-uniform trip count
+    const int t = t0 + grp;
+    const bool item = t < total;
+    int i = 0;                                             // the item's row: the last one with ofs <= t
+#pragma unroll
+    for (int k = 1; k < G; ++k) i += t >= __builtin_amdgcn_readlane(ofs_l, k) ? 1 : 0;     // (rows past n_rows: ofs = total > t)
+    const int rb = __shfl(rp_l, i, 64), re = __shfl(rp_l, i + 1, 64);
+    const int o_i = __shfl(ofs_l, i, 64), n_i = __shfl(it_l, i, 64);
+    const int b = rb + (t - o_i) * ch;
+    const float4 acc = gather(b, item ? min(ch, re - b) : 0);      // (0 entries: an empty row or no item)
+    if (item) {
+      if (n_i == 1) finish(row0 + i, acc);
+      else part[t][gl] = acc;
+    }
+  }
+  __syncthreads();
+  const int o_g = __shfl(ofs_l, grp, 64), n_g = __shfl(it_l, grp, 64);
+  if (n_g > 1) {                                           // a split row: its items in order
+    float4 acc = part[o_g][gl];
+    for (int c = 1; c < n_g; ++c) {
+      const float4 p = part[o_g + c][gl];
+      acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+    }
+    finish(row, acc);
   }
 }
 
@@ -471,7 +546,7 @@ int isic_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* va
   const bool al16_all = al16 && ((reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(addend)) & 15) == 0;
   if (F % 4 == 0 && F <= 256 && al16_all) {
     const int lpr = F <= 64 ? 16 : (F <= 128 ? 32 : 64);
-    const int rows_per_block = (SPMM_THREADS / 64) * (64 / lpr);
+    const int rows_per_block = SPMM_THREADS / lpr;
     const dim3 g2((unsigned)((((n_rows + rows_per_block - 1) / rows_per_block) + 7) / 8 * 8));   // multiple of 8: bijective XCD remap
     if (lpr == 16) hipLaunchKernelGGL(spmm_group_kernel<16>, g2, dim3(SPMM_THREADS), 0, s, rowptr, col, val, x, bias, out, n_rows, F, alpha, addend, addend_scale);
     else if (lpr == 32) hipLaunchKernelGGL(spmm_group_kernel<32>, g2, dim3(SPMM_THREADS), 0, s, rowptr, col, val, x, bias, out, n_rows, F, alpha, addend, addend_scale);

@@ -125,6 +125,38 @@ def test_spmm_large_batch_of_graphs(F):
     assert_close(xd.grad, x.grad, rtol=2e-5, atol=2e-6, what="dx")
 
 
+@pytest.mark.parametrize("F", [128, 64, 256])
+def test_spmm_hub_rows_are_split_and_reproducible(F):
+    """k-NN hubness: rows of 1 .. 700 entries in one orientation (the grouped SpMM cuts rows of more than 16 entries into
+    items whose partial sums are added in item order; more than 32 items per block doubles the item length) vs
+    oracle.gcn_conv, forward and backward, and bit-equal from run to run."""
+    from isic_hip.graph import GraphBatch, spmm
+    gen = torch.Generator().manual_seed(17)
+    n = 800
+    src = [torch.randint(0, n, (6 * n,), generator=gen)]
+    dst = [torch.randint(0, n, (6 * n,), generator=gen)]
+    for hub, deg in ((5, 700), (6, 130), (7, 33), (8, 17), (300, 64), (301, 48), (799, 260)):     # 5..8 share a block
+        src.append(torch.randperm(n, generator=gen)[:deg])
+        dst.append(torch.full((deg,), hub, dtype=torch.int64))
+    ei = torch.stack([torch.cat(src), torch.cat(dst)])
+    x = torch.randn(n, F, generator=gen, requires_grad=True)
+    bias = torch.randn(F, generator=gen, requires_grad=True)
+    ref = gnn.gcn_conv(x, ei, None, torch.eye(F), bias)
+    dy = torch.randn(n, F, generator=gen)
+    ref.backward(dy)
+    gb = GraphBatch(ei.to(DEV), n)
+    outs = []
+    for _ in range(2):
+        xd = x.detach().to(DEV).requires_grad_(True)
+        bd = bias.detach().to(DEV).requires_grad_(True)
+        out = spmm(xd, gb, bias=bd)
+        out.backward(dy.to(DEV))
+        outs.append((out.detach().clone(), xd.grad.clone()))
+    assert_close(outs[0][0], ref, rtol=2e-5, atol=4e-6, what="A^x+b with hubs")
+    assert_close(outs[0][1], x.grad, rtol=2e-5, atol=4e-6, what="dx with hubs")
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("tag", ["small", "ref", "same"])
 def test_graphmil_mlp_golden(tag):
     from gnn_models import GraphMIL
