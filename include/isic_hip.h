@@ -85,6 +85,14 @@ int isic_relu_dropout_fwd_f32(float* x, int64_t n, uint32_t drop_threshold, floa
                               uint64_t stream_id, void* stream);
 int isic_relu_dropout_bwd_f32(const float* y, float* dy, int64_t n, float drop_scale, void* stream);
 
+/* dst[i][0..count[i]) = (accumulate ? dst[i] : 0) + src[i][0..count[i])  for nseg <= 32 segments in ONE launch.  dst, src and
+ * count are HOST arrays (read during the call; the pointers in them are device pointers).  The per-head attention
+ * parameters of GraphMIL (05_train_gnns.py:126-131: heads x {Linear, Linear}) are gathered into the fused [heads*A, H] operands
+ * with one launch, and their gradients scattered back into the parameters' .grad with one, instead of 4 concatenations and 16
+ * accumulation kernels per step. */
+int isic_multi_copy_f32(int nseg, float* const* dst, const float* const* src, const int64_t* count, int accumulate,
+                        void* stream);
+
 /* ------------------------------------------------------------------ device step clock (captured train steps)
  * A train step captured into a hipGraph replays the SAME kernel arguments, but two values must change from step to
  * step: the dropout stream id (step * 1024 + site, oracle/philox.py) and Adam's step count t.  The `_clk` forms of the
@@ -124,6 +132,16 @@ int isic_attn_pool_bwd(const float* h, const float* t, const float* att, const f
                        const float* w3, const float* W4, const int64_t* offsets, int B, int H, int A, int heads,
                        int C, int max_bag, const float* d_bag_logits, const float* d_z, float* d_h,
                        int accumulate_dh, float* d_u, float* d_s, float* d_P, void* stream);
+/* ... that also takes the column sums the attention parameters' gradients need while d_u and t are in registers:
+ * param_sums[B][2*heads*A + heads] = per bag, summed over the bag's rows in a fixed order:  d_u  |  d_s[., k] * t[., k*A + j]  |
+ * d_s.  Summed over the bags (isic_colsum_f32) they ARE db2 (first Linear's bias), dw3 (second Linear's weight, [heads][A])
+ * and db3 -- instead of a [heads x heads*A x T] product of which only the block diagonal is used, two column-sum passes
+ * over d_u / d_s and a concatenation (05_train_gnns.py:126-139's autograd backward).  H <= 128, A <= 128, d_u != NULL;
+ * ISIC_ERR_UNSUPPORTED otherwise.  param_sums == NULL: isic_attn_pool_bwd. */
+int isic_attn_pool_bwd_sums(const float* h, const float* t, const float* att, const float* patch_logits,
+                            const float* w3, const float* W4, const int64_t* offsets, int B, int H, int A, int heads,
+                            int C, int max_bag, const float* d_bag_logits, const float* d_z, float* d_h,
+                            int accumulate_dh, float* d_u, float* d_s, float* d_P, float* param_sums, void* stream);
 
 /* ------------------------------------------------------------------ LayerNorm (+ReLU +dropout +residual)
  * y = dropout(relu?(LN(x) * gamma + beta)) + residual      rows of length N.

@@ -241,9 +241,10 @@ struct PoolBwdArgs {
   int B, H, A, heads, C, max_bag;
   const float* d_bag_logits; const float* d_z;
   float* d_h; int accumulate_dh; float* d_u; float* d_s; float* d_P;
+  float* psum;        // FAST only: [B][2 * heads * A + heads] per-bag sums over the bag's rows of d_u | d_s * t | d_s, or NULL
 };
 
-// LDS (floats): w3s[heads*A] | W4s[C*H] | dzs[H] | da[max_bag*heads] | red[NWAVE_B*heads]
+// LDS (floats): w3s[heads*A] | W4s[C*H] | dzs[H] | da[max_bag*heads] | red[NWAVE_B*heads] | psum: wred[NWAVE_B][2*heads*A + heads]
 // FAST: H <= 128 and A <= 128 -- the h / attention-hidden values of a row are fetched up front (two per lane and head)
 // instead of through runtime-length loops of dependent loads (as attn_pool_fwd_kernel<JH, 2>)
 template <bool FAST>
@@ -316,6 +317,11 @@ __global__ __launch_bounds__(NTHR_B) void attn_pool_bwd_kernel(PoolBwdArgs a) {
 
   // pass 2
   const int At = NH * A;
+  // (psum) the column sums the parameter gradients need -- db2 = sum_n d_u, dw3 = sum_n d_s * t, db3 = sum_n d_s -- are
+  // taken HERE, where d_u and t are in registers: a lane owns columns lane, lane + 64 of every head, a wave its rows
+  float su[MAX_HEADS][2], sw[MAX_HEADS][2], ssum[MAX_HEADS];
+#pragma unroll
+  for (int k = 0; k < MAX_HEADS; ++k) { su[k][0] = su[k][1] = sw[k][0] = sw[k][1] = 0.f; ssum[k] = 0.f; }
   for (int n = wave; n < nb; n += NWAVE_B) {
     float an[MAX_HEADS], ds[MAX_HEADS];
 #pragma unroll
@@ -344,8 +350,15 @@ __global__ __launch_bounds__(NTHR_B) void attn_pool_bwd_kernel(PoolBwdArgs a) {
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             const int j = lane + 64 * i;
-            if (k < NH && j < A) urow[k * A + j] = ds[k] * w3s[k * A + j] * (1.f - tv[k][i] * tv[k][i]);
+            if (k < NH && j < A) {
+              const float uv = ds[k] * w3s[k * A + j] * (1.f - tv[k][i] * tv[k][i]);
+              urow[k * A + j] = uv;
+              su[k][i] += uv;
+              sw[k][i] += ds[k] * tv[k][i];
+            }
           }
+#pragma unroll
+        for (int k = 0; k < MAX_HEADS; ++k) ssum[k] += ds[k];
       } else {
 #pragma unroll
         for (int k = 0; k < MAX_HEADS; ++k) if (k < NH) {
@@ -376,6 +389,29 @@ __global__ __launch_bounds__(NTHR_B) void attn_pool_bwd_kernel(PoolBwdArgs a) {
         }
         drow[j] = a.accumulate_dh ? drow[j] + v : v;
       }
+    }
+  }
+  if (FAST && a.psum) {                                      // block-uniform
+    const int PW = 2 * At + NH;
+    float* wred = red + NWAVE_B * NH + wave * PW;
+#pragma unroll
+    for (int k = 0; k < MAX_HEADS; ++k)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int j = lane + 64 * i;
+        if (k < NH && j < A) { wred[k * A + j] = su[k][i]; wred[At + k * A + j] = sw[k][i]; }
+      }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < MAX_HEADS; ++k) if (k < NH) wred[2 * At + k] = ssum[k];
+    }
+    __syncthreads();
+    const float* w0 = red + NWAVE_B * NH;
+    for (int c = tid; c < PW; c += NTHR_B) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWAVE_B; ++w) v += w0[w * PW + c];   // fixed order: the bag's sum does not depend on timing
+      a.psum[(size_t)b * PW + c] = v;
     }
   }
 }
@@ -436,6 +472,14 @@ int isic_attn_pool_bwd(const float* h, const float* t, const float* att, const f
                        const float* w3, const float* W4, const int64_t* offsets, int B, int H, int A, int heads,
                        int C, int max_bag, const float* d_bag_logits, const float* d_z, float* d_h,
                        int accumulate_dh, float* d_u, float* d_s, float* d_P, void* stream) {
+  return isic_attn_pool_bwd_sums(h, t, att, patch_logits, w3, W4, offsets, B, H, A, heads, C, max_bag, d_bag_logits, d_z, d_h,
+                                 accumulate_dh, d_u, d_s, d_P, nullptr, stream);
+}
+
+int isic_attn_pool_bwd_sums(const float* h, const float* t, const float* att, const float* patch_logits,
+                            const float* w3, const float* W4, const int64_t* offsets, int B, int H, int A, int heads,
+                            int C, int max_bag, const float* d_bag_logits, const float* d_z, float* d_h,
+                            int accumulate_dh, float* d_u, float* d_s, float* d_P, float* param_sums, void* stream) {
   ISIC_CHECK_ARG(B >= 0 && H > 0 && A > 0 && heads > 0 && max_bag >= 0);
   if (B == 0) return ISIC_OK;
   ISIC_CHECK_ARG(h && t && att && w3 && offsets);
@@ -445,9 +489,10 @@ int isic_attn_pool_bwd(const float* h, const float* t, const float* att, const f
   a.h = h; a.t = t; a.att = att; a.P = patch_logits; a.w3 = w3; a.W4 = W4; a.offsets = offsets;
   a.B = B; a.H = H; a.A = A; a.heads = heads; a.C = W4 ? C : 0; a.max_bag = max_bag;
   a.d_bag_logits = d_bag_logits; a.d_z = d_z; a.d_h = d_h; a.accumulate_dh = accumulate_dh;
-  a.d_u = d_u; a.d_s = d_s; a.d_P = d_P;
+  a.d_u = d_u; a.d_s = d_s; a.d_P = d_P; a.psum = param_sums;
+  if (param_sums && !(H <= 128 && A <= 128 && d_u)) return ISIC_ERR_UNSUPPORTED;      // the sums are taken by the two-columns-per-lane form
   const size_t lds = sizeof(float) * ((size_t)heads * A + (W4 ? (size_t)C * H : 0) + H + (size_t)max_bag * heads +
-                                      NWAVE_B * heads);
+                                      NWAVE_B * heads + (param_sums ? (size_t)NWAVE_B * (2 * heads * A + heads) : 0));
   int rc;
   if (H <= 128 && A <= 128) {
     rc = ensure_lds(attn_pool_bwd_kernel<true>, lds);

@@ -19,6 +19,12 @@ int isic_gemm_f32p_launch(int transA, int transB, int M, int N, int K, const flo
                           float* C, int ldc, const float* bias, int act, float beta, void* workspace,
                           size_t workspace_bytes, hipStream_t stream);
 
+// register-fed split-K kernel for A^T B with a small output and a long reduction (gemm_f32t.hip)
+size_t isic_gemm_f32t_workspace_bytes(int transA, int transB, int M, int N, int K);
+int isic_gemm_f32t_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                          float* C, int ldc, const float* bias, int act, float beta, void* workspace,
+                          size_t workspace_bytes, int force, hipStream_t stream);
+
 namespace {
 
 constexpr int BM = 64, BN = 64, BK = 16, LDT = BK + 4;  // 80-byte rows: 16-B aligned, conflict-light
@@ -290,6 +296,17 @@ __global__ void relu_dropout_bwd_kernel(const float* __restrict__ y, float* __re
   for (; i < n; i += stride) dy[i] = y[i] > 0.f ? dy[i] * scale : 0.f;
 }
 
+// up to 32 (dst, src, count) segments in one launch: blockIdx.y = segment
+struct MultiCopyArgs { float* dst[32]; const float* src[32]; long long count[32]; int accumulate; };
+__global__ __launch_bounds__(256) void multi_copy_kernel(MultiCopyArgs a) {
+  const int sgm = blockIdx.y;
+  float* __restrict__ d = a.dst[sgm];
+  const float* __restrict__ s = a.src[sgm];
+  const long long n = a.count[sgm];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    d[i] = a.accumulate ? d[i] + s[i] : s[i];
+}
+
 // split K when a long reduction meets a small output (weight gradients dW = dY^T X over all the nodes of a batch):
 // a handful of 64x64 tiles would otherwise walk tens of thousands of k on a handful of CUs
 inline int small_split_plan(int M, int N, int K, bool plain, int* klen) {
@@ -311,16 +328,24 @@ inline int grid_for(int64_t n, int block) {
 
 }  // namespace
 
+void isic_gemm_split_reduce_launch(const float* partial, int splits, float* C, int M, int N, int ldc, float beta,
+                                   hipStream_t stream) {
+  hipLaunchKernelGGL(gemm_split_reduce_kernel, dim3((unsigned)ceil_div64((int64_t)M * N, 16)), dim3(256), 0, stream, partial,
+                     splits, C, M, N, ldc, beta);
+}
+
 extern "C" {
 
 size_t isic_gemm_f32_workspace_bytes(int transA, int transB, int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const size_t t = isic_gemm_f32t_workspace_bytes(transA, transB, M, N, K);
   const size_t p = isic_gemm_f32p_workspace_bytes(transA, transB, M, N, K);
   // the 64 x 64 kernel's own split-K (small_split_plan: a long reduction onto < 512 tiles, no bias / activation)
   int klen = 0;
   const int ks = small_split_plan(M, N, K, true, &klen);
   const size_t q = ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
-  return p > q ? p : q;
+  const size_t pq = p > q ? p : q;
+  return t > pq ? t : pq;                                    // whichever kernel the launch ends up with
 }
 
 int isic_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
@@ -338,11 +363,16 @@ int isic_gemm_f32_ws(int transA, int transB, int M, int N, int K, const float* A
 int isic_test_gemm_f32_variant(int variant, int transA, int transB, int M, int N, int K, const float* A, int lda,
                                const float* B, int ldb, float* C, int ldc, const float* bias, int act, float beta,
                                void* workspace, size_t workspace_bytes, void* stream) {
-  ISIC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && variant >= 0 && variant <= 2);
+  ISIC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && variant >= 0 && variant <= 3);
   if (M == 0 || N == 0) return ISIC_OK;
   ISIC_CHECK_ARG(A && B && C);
   ISIC_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N);
   ISIC_CHECK_ARG(act >= ISIC_ACT_NONE && act <= ISIC_ACT_TANH);
+  if (variant == 0 || variant == 3) {
+    const int rc = isic_gemm_f32t_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, beta, workspace,
+                                         workspace_bytes, variant == 3, as_stream(stream));
+    if (rc != ISIC_ERR_UNSUPPORTED || variant == 3) return rc;
+  }
   if (variant != 1) {
     const int rc = isic_gemm_f32p_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, beta, workspace,
                                          workspace_bytes, as_stream(stream));
@@ -370,6 +400,23 @@ int isic_test_gemm_f32_variant(int variant, int transA, int transB, int M, int N
   if (a.partial)
     hipLaunchKernelGGL(gemm_split_reduce_kernel, dim3((unsigned)ceil_div64((int64_t)M * N, 16)), dim3(256), 0, as_stream(stream),
                        a.partial, a.ksplit, C, M, N, ldc, beta);
+  return isic_launch_status();
+}
+
+int isic_multi_copy_f32(int nseg, float* const* dst, const float* const* src, const int64_t* count, int accumulate,
+                        void* stream) {
+  ISIC_CHECK_ARG(nseg >= 0 && nseg <= 32);
+  if (nseg == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(dst && src && count);
+  MultiCopyArgs a;
+  long long mx = 0;
+  for (int i = 0; i < 32; ++i) {
+    a.dst[i] = i < nseg ? dst[i] : nullptr; a.src[i] = i < nseg ? src[i] : nullptr; a.count[i] = i < nseg ? count[i] : 0;
+    if (i < nseg) { ISIC_CHECK_ARG(count[i] >= 0 && (count[i] == 0 || (dst[i] && src[i]))); if (count[i] > mx) mx = count[i]; }
+  }
+  a.accumulate = accumulate;
+  if (mx == 0) return ISIC_OK;
+  hipLaunchKernelGGL(multi_copy_kernel, dim3(grid_for(mx, 256) > 64 ? 64 : grid_for(mx, 256), nseg), dim3(256), 0, as_stream(stream), a);
   return isic_launch_status();
 }
 

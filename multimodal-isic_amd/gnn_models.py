@@ -287,10 +287,7 @@ class GraphMIL(nn.Module):
                 if res is not None:
                     h = h + res
         self.last_node_embeddings = h.detach()
-        W2 = torch.cat([a[0].weight for a in self.attention_layers], dim=0)
-        b2 = torch.cat([a[0].bias for a in self.attention_layers], dim=0)
-        w3 = torch.cat([a[2].weight for a in self.attention_layers], dim=0)
-        b3 = torch.cat([a[2].bias for a in self.attention_layers], dim=0)
+        W2, b2, w3, b3 = ops.head_params(self.attention_layers)      # the heads' parameters as one [heads*A, H] operand
         z, att = ops.attn_pool(h, W2, b2, w3, b3, offs.device, offs.max_bag, heads=self.att_heads)
         c = self.classifier
         if self.classifier_light:

@@ -6,6 +6,7 @@ are rejected (no fallback).
 """
 from __future__ import annotations
 
+import ctypes
 import math
 
 import torch
@@ -222,6 +223,70 @@ def relu_dropout(x, drop=None):
     return ReluDropoutFn.apply(x, drop)
 
 
+# --------------------------------------------------------------------------- many small tensors, one launch
+def multi_copy(dsts, srcs, accumulate=False):
+    """dst[i] (+)= src[i] for up to 32 dense fp32 device tensors of equal sizes pairwise, in ONE launch."""
+    n = len(dsts)
+    if n != len(srcs):
+        raise ValueError("multi_copy: as many sources as destinations")
+    for lo in range(0, n, 32):
+        d, s_ = dsts[lo:lo + 32], srcs[lo:lo + 32]
+        for x, y in zip(d, s_):
+            _chk(x, y)
+            if x.numel() != y.numel() or x.dtype != torch.float32 or y.dtype != torch.float32 or not x.is_contiguous() \
+                    or not y.is_contiguous():
+                raise IsicHipError("multi_copy takes dense fp32 tensors of pairwise equal sizes")
+        m = len(d)
+        dp = (ctypes.c_void_p * m)(*[x.data_ptr() for x in d])
+        sp = (ctypes.c_void_p * m)(*[y.data_ptr() for y in s_])
+        cn = (ctypes.c_int64 * m)(*[x.numel() for x in d])
+        call("isic_multi_copy_f32", m, ctypes.addressof(dp), ctypes.addressof(sp), ctypes.addressof(cn), int(accumulate))
+
+
+class HeadParamsFn(torch.autograd.Function):
+    """The per-head attention parameters (`05_train_gnns.py:126-131`: heads x Sequential(Linear(H, A), Tanh, Linear(A, 1)))
+    as the fused operands of ``attn_pool``: (W_0, b_0, w_0, c_0, W_1, ...) -> W2[heads*A, H], b2[heads*A], w3[heads, A],
+    b3[heads].  One gather launch forward; backward one scatter launch that adds the slices into the parameters' ``.grad``
+    (under ``fused_grad_accumulation``) -- instead of four concatenations and 4 * heads AccumulateGrad kernels."""
+
+    @staticmethod
+    def forward(ctx, *params):
+        _chk(*params)
+        heads = len(params) // 4
+        A, H = params[0].shape
+        nW, nb = heads * A * H, heads * A
+        flat = torch.empty(nW + 2 * nb + heads, device=params[0].device, dtype=torch.float32)
+        W2, b2 = flat[:nW].view(heads * A, H), flat[nW:nW + nb]
+        w3, b3 = flat[nW + nb:nW + 2 * nb].view(heads, A), flat[nW + 2 * nb:]
+        dst = []
+        for k in range(heads):
+            dst += [W2[k * A:(k + 1) * A], b2[k * A:(k + 1) * A], w3[k], b3[k:k + 1]]
+        multi_copy(dst, [_f32c(p.detach()) for p in params])
+        ctx.params, ctx.dims = params, (heads, A, H)
+        return W2, b2, w3, b3
+
+    @staticmethod
+    def backward(ctx, gW2, gb2, gw3, gb3):
+        heads, A, H = ctx.dims
+        gs = []
+        for k in range(heads):
+            gs += [None if gW2 is None else gW2[k * A:(k + 1) * A], None if gb2 is None else gb2[k * A:(k + 1) * A],
+                   None if gw3 is None else gw3.reshape(heads, A)[k], None if gb3 is None else gb3.reshape(heads)[k:k + 1]]
+        tg = [_acc_target(p) for p in ctx.params]
+        if all(t is not None for t in tg) and all(g is not None and g.is_contiguous() for g in gs):
+            multi_copy(tg, gs, accumulate=True)
+            return (None,) * len(ctx.params)
+        return tuple(None if g is None else g.reshape(p.shape) for g, p in zip(gs, ctx.params))
+
+
+def head_params(attention_layers):
+    """Fused attn_pool operands of a ModuleList of Sequential(Linear, Tanh, Linear) heads."""
+    ps = []
+    for a in attention_layers:
+        ps += [a[0].weight, a[0].bias, a[2].weight, a[2].bias]
+    return HeadParamsFn.apply(*ps)
+
+
 # --------------------------------------------------------------------------- attention pool
 class AttnPoolFn(torch.autograd.Function):
     """Attention scores + segmented softmax + pooling over ragged bags.
@@ -278,18 +343,28 @@ class AttnPoolFn(torch.autograd.Function):
         d_u = torch.empty((T, heads * A), device=dev, dtype=torch.float32)
         d_s = torch.empty((T, heads), device=dev, dtype=torch.float32)
         d_P = torch.empty((T, C), device=dev, dtype=torch.float32) if ctx.teacher else None
-        call("isic_attn_pool_bwd", h, t, att, P, w3c, W4c, offsets, B, H, A, heads, C, max_bag, dBL, dz, d_h, 0, d_u,
-             d_s, d_P)
-        # weight gradients: plain GEMMs / column sums over the T instances
-        dW2 = gemm(d_u, h, trans_a=True)                     # [heads*A, H]
-        db2 = colsum(d_u)
-        # dw3[k, j] = sum_n d_s[n,k] * t[n, k*A + j]
-        if heads == 1:
-            dw3 = gemm(d_s, t, trans_a=True)                 # [1, A]
+        if H <= 128 and A <= 128:
+            # db2 = sum_n d_u, dw3[k, j] = sum_n d_s[n,k] t[n, kA+j], db3 = sum_n d_s: per-bag sums out of the pool kernel
+            # (d_u and t are in its registers), then ONE column sum over the bags
+            nA = heads * A
+            psum = torch.empty((B, 2 * nA + heads), device=dev, dtype=torch.float32)
+            call("isic_attn_pool_bwd_sums", h, t, att, P, w3c, W4c, offsets, B, H, A, heads, C, max_bag, dBL, dz, d_h, 0,
+                 d_u, d_s, d_P, psum)
+            sums = colsum(psum)
+            db2, dw3, db3 = sums[:nA], sums[nA:2 * nA].view(heads, A), sums[2 * nA:]
         else:
-            full = gemm(d_s, t, trans_a=True)                # [heads, heads*A]
-            dw3 = torch.stack([full[k, k * A:(k + 1) * A] for k in range(heads)])
-        db3 = colsum(d_s)
+            call("isic_attn_pool_bwd", h, t, att, P, w3c, W4c, offsets, B, H, A, heads, C, max_bag, dBL, dz, d_h, 0, d_u,
+                 d_s, d_P)
+            db2 = colsum(d_u)
+            # dw3[k, j] = sum_n d_s[n,k] * t[n, k*A + j]
+            if heads == 1:
+                dw3 = gemm(d_s, t, trans_a=True)                 # [1, A]
+            else:
+                full = gemm(d_s, t, trans_a=True)                # [heads, heads*A]
+                dw3 = torch.stack([full[k, k * A:(k + 1) * A] for k in range(heads)])
+            db3 = colsum(d_s)
+        # weight gradient of the first Linear: a GEMM over the T instances
+        dW2 = gemm(d_u, h, trans_a=True)                     # [heads*A, H]
         gemm(d_u, W2, out=d_h, beta=1.0)                     # d_h += d_u W2
         dW4 = db4 = None
         if ctx.teacher:

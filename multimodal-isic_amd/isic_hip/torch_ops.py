@@ -243,13 +243,21 @@ def attn_pool_backward(dz: Tensor, h: Tensor, t: Tensor, att: Tensor, W2: Tensor
     d_h = torch.empty((T, H), device=h2.device, dtype=torch.float32)
     d_u = torch.empty((T, heads * A), device=h2.device, dtype=torch.float32)
     d_s = torch.empty((T, heads), device=h2.device, dtype=torch.float32)
-    call("isic_attn_pool_bwd", h2, t, att, None, _c(w3).reshape(heads, A), None, offsets, B, H, A, heads, 0, int(max_bag), None,
-         _c(dz), d_h, 0, d_u, d_s, None)
+    if H <= 128 and A <= 128:                                             # as ops.AttnPoolFn: per-bag sums out of the pool kernel
+        nA = heads * A
+        psum = torch.empty((B, 2 * nA + heads), device=h2.device, dtype=torch.float32)
+        call("isic_attn_pool_bwd_sums", h2, t, att, None, _c(w3).reshape(heads, A), None, offsets, B, H, A, heads, 0, int(max_bag),
+             None, _c(dz), d_h, 0, d_u, d_s, None, psum)
+        sums = _o.colsum(psum)
+        db2, dw3, db3 = sums[:nA].clone(), sums[nA:2 * nA].reshape(w3.shape).clone(), sums[2 * nA:].clone()
+    else:
+        call("isic_attn_pool_bwd", h2, t, att, None, _c(w3).reshape(heads, A), None, offsets, B, H, A, heads, 0, int(max_bag), None,
+             _c(dz), d_h, 0, d_u, d_s, None)
+        db2 = _o.colsum(d_u)
+        full = _o.gemm(d_s, t, trans_a=True)                               # [heads, heads*A]
+        dw3 = torch.stack([full[k, k * A:(k + 1) * A] for k in range(heads)]).reshape(w3.shape)
+        db3 = _o.colsum(d_s)
     dW2 = _o.gemm(d_u, h2, trans_a=True)
-    db2 = _o.colsum(d_u)
-    full = _o.gemm(d_s, t, trans_a=True)                                   # [heads, heads*A]
-    dw3 = torch.stack([full[k, k * A:(k + 1) * A] for k in range(heads)]).reshape(w3.shape)
-    db3 = _o.colsum(d_s)
     _o.gemm(d_u, W2c, out=d_h, beta=1.0)
     return d_h, dW2, db2, dw3, db3
 

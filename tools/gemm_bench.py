@@ -1,5 +1,7 @@
 """A/B timing of the fp32 GEMM kernels on the graph path's products (256 graphs x 196 nodes per step; developer tool):
-the 64 x 64 x 16 register-staged kernel (gemm_f32.hip) vs the persistent 256 x 128 x 32 LDS-DMA kernel (gemm_f32p.hip).
+the 64 x 64 x 16 register-staged kernel (gemm_f32.hip), the persistent 256 x 128 x 32 LDS-DMA kernel (gemm_f32p.hip), the
+register-fed A^T B split-K kernel (gemm_f32t.hip), the row-panel kernel for K <= 128 (gemm_f32r.hip) and the shipped choice;
+every result is also compared with an fp64 product.
 
     python tools/gemm_bench.py [--iters 20]
 """
@@ -28,28 +30,37 @@ SHAPES = [  # (name, M, N, K, transA, transB, bias)
 ]
 
 
+VARIANTS = [(1, "64x64x16"), (2, "persistent"), (3, "A^T B regs"), (4, "row-panel"), (0, "shipped")]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     a = ap.parse_args()
     ws = torch.empty(256 << 20, device=DEV, dtype=torch.uint8)
-    print(f"{'product':28s} {'M':>6s} {'N':>5s} {'K':>6s}   old us  TF/s   new us  TF/s  frac   speed-up")
+    print(f"{'product':24s} {'M':>6s} {'N':>5s} {'K':>6s} " + " ".join(f"{n:>17s}" for _, n in VARIANTS) + "   (us, fraction of 157.3 TFLOP/s; max |err| vs fp64)")
     for name, M, N, K, ta, tb, hb in SHAPES:
         A = torch.randn((K, M) if ta else (M, K), device=DEV)
         B = torch.randn((N, K) if tb else (K, N), device=DEV)
         C = torch.empty(M, N, device=DEV)
         bias = torch.randn(N, device=DEV) if hb else None
-        res = []
-        for variant in (1, 2):
+        ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
+        if hb:
+            ref = ref + bias.double()
+        fl = 2.0 * M * N * K
+        cells = []
+        for variant, _ in VARIANTS:
             def run():
                 call("isic_test_gemm_f32_variant", variant, ta, tb, M, N, K, A, A.shape[1], B, B.shape[1], C, N, bias, 0, 0.0,
                      ws, ws.numel())
             try:
+                C.fill_(float("nan"))
                 for _ in range(3):
                     run()
             except IsicHipError:
-                res.append(None)
+                cells.append(f"{'--':>17s}")
                 continue
+            err = (C.double() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -57,12 +68,9 @@ def main():
                 run()
             e1.record()
             torch.cuda.synchronize()
-            res.append(e0.elapsed_time(e1) / a.iters * 1e3)
-        fl = 2.0 * M * N * K
-        f = lambda us: "    --    --" if us is None else f"{us:8.1f} {fl / us / 1e6:5.1f}"
-        frac = "  -- " if res[1] is None else f"{fl / res[1] / 1e6 / PEAK:5.2f}"
-        sp = "" if None in res else f"{res[0] / res[1]:6.2f}x"
-        print(f"{name:28s} {M:6d} {N:5d} {K:6d} {f(res[0])} {f(res[1])} {frac}   {sp}")
+            us = e0.elapsed_time(e1) / a.iters * 1e3
+            cells.append(f"{us:7.1f} {fl / us / 1e6 / PEAK:4.2f} {err:4.0e}")
+        print(f"{name:24s} {M:6d} {N:5d} {K:6d} " + " ".join(cells))
 
 
 if __name__ == "__main__":
