@@ -66,6 +66,12 @@ size_t isic_gemm_f32_workspace_bytes(int transA, int transB, int M, int N, int K
 int isic_gemm_f32_ws(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                      float* C, int ldc, const float* bias, int act, float beta, void* workspace, size_t workspace_bytes,
                      void* stream);
+/* ... + addend[M, N] (leading dimension ldadd; NULL: isic_gemm_f32_ws) added to the result: the second gradient path of a
+ * residual connection joins in the GEMM's epilogue instead of in an elementwise pass over both
+ * (05_train_gnns.py:187-199: h = h_prev + dropout(relu(LN(conv(h_prev)))) -> dh_prev = dY + dConv W). */
+int isic_gemm_f32_add_ws(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                         float* C, int ldc, const float* bias, int act, float beta, const float* addend, int ldadd,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* out[n] = sum_m X[m,n] (+ beta*out): bias gradients of the layers above. */
 int isic_colsum_f32(const float* X, int M, int N, int ldx, float* out, float beta, void* stream);
@@ -172,6 +178,15 @@ int isic_layernorm_bwd_ws(const float* dy, const float* x, const float* gamma, c
                           const float* rstd, float* dx, float* dgamma, float* dbeta, int M, int N, int relu,
                           uint32_t drop_threshold, float drop_scale, uint64_t seed, uint64_t stream_id,
                           const uint64_t* clock, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ... that also ACCUMULATES (+=) the column sums of dx into dxsum[N]: when the normalised tensor is A^ (h W^T) + b, they are
+ * the gradient of the bias b (GCNConv's, 05_train_gnns.py:82,184-187) -- taken while dx is in registers instead of by a
+ * column-sum pass over it.  N in {64, 128, 256}, 16-byte aligned, workspace required (ISIC_ERR_UNSUPPORTED / _WORKSPACE
+ * otherwise); dxsum == NULL: isic_layernorm_bwd_ws. */
+int isic_layernorm_bwd_dxsum_ws(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
+                                const float* rstd, float* dx, float* dgamma, float* dbeta, float* dxsum, int M, int N,
+                                int relu, uint32_t drop_threshold, float drop_scale, uint64_t seed, uint64_t stream_id,
+                                const uint64_t* clock, void* workspace, size_t workspace_bytes, void* stream);
 
 /* y = x / max(||x||_2, eps) per row and its backward: F.normalize of
  * SAGEConv(normalize=True) (05_train_gnns.py:87-88). */

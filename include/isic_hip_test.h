@@ -29,7 +29,7 @@ int isic_test_conv2d_igemm_variant_bf16(const uint16_t* in, const uint16_t* w, u
 /* isic_gemm_f32_ws (same arguments) with the kernel pinned: variant 0 = shipped choice, 1 = always the 64 x 64 x 16
  * register-staged kernel (split-K through fp32 atomics), 2 = the persistent 256 x 128 x 32 kernel or
  * ISIC_ERR_UNSUPPORTED when the shape is not for it, 3 = the register-fed A^T B split-K kernel (small output, long
- * reduction) or ISIC_ERR_UNSUPPORTED.  A/B timing (tools/gemm_bench.py) and tests only. */
+ * reduction) or ISIC_ERR_UNSUPPORTED, 4 = the row-panel kernel (long M, K <= 128) or ISIC_ERR_UNSUPPORTED.  A/B timing (tools/gemm_bench.py) and tests only. */
 int isic_test_gemm_f32_variant(int variant, int transA, int transB, int M, int N, int K, const float* A, int lda,
                                const float* B, int ldb, float* C, int ldc, const float* bias, int act, float beta,
                                void* workspace, size_t workspace_bytes, void* stream);

@@ -25,6 +25,11 @@ int isic_gemm_f32t_launch(int transA, int transB, int M, int N, int K, const flo
                           float* C, int ldc, const float* bias, int act, float beta, void* workspace,
                           size_t workspace_bytes, int force, hipStream_t stream);
 
+// row-panel kernel for a long M and K <= 128 (gemm_f32r.hip)
+int isic_gemm_f32r_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                          float* C, int ldc, const float* bias, int act, float beta, const float* addend, int ldadd,
+                          hipStream_t stream);
+
 namespace {
 
 constexpr int BM = 64, BN = 64, BK = 16, LDT = BK + 4;  // 80-byte rows: 16-B aligned, conflict-light
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
         if (row >= a.M) continue;
         float v = acc[i][j][r] + bv;
         if (a.act == ISIC_ACT_RELU) v = fmaxf(v, 0.f);
-        else if (a.act == ISIC_ACT_TANH) v = tanhf(v);
+        else if (a.act == ISIC_ACT_TANH) v = isic_tanhf(v);
         float* cp = a.C + (size_t)row * a.ldc + col;
         if (a.ksplit > 1) {
           if (a.partial) a.partial[((size_t)blockIdx.z * a.M + row) * a.N + col] = v;      // deterministic: own slot
@@ -194,6 +199,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     float t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
     if (gridDim.y > 1) atomicAdd(out + col, t);
     else out[col] = beta != 0.f ? beta * out[col] + t : t;
+  }
+}
+
+// A SHORT matrix (M < 8192 rows: bias gradients over the bags / graphs of a batch, the per-bag sums of the attention pool): 16
+// waves stride the rows with four loads in flight each -- the 4-wave kernel above walks 64 dependent row loads per wave for
+// 256 rows (12 us; this one 3) -- and are added in wave order: bit-reproducible.
+__global__ __launch_bounds__(1024) void colsum_small_kernel(const float* __restrict__ X, int M, int N, int ldx,
+                                                             float* __restrict__ out, float beta) {
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < N) {
+    const float* p = X + col;
+    int r = wave;
+    for (; r + 48 < M; r += 64) {
+      s0 += p[(size_t)r * ldx]; s1 += p[(size_t)(r + 16) * ldx]; s2 += p[(size_t)(r + 32) * ldx]; s3 += p[(size_t)(r + 48) * ldx];
+    }
+    for (; r < M; r += 16) s0 += p[(size_t)r * ldx];
+  }
+  part[wave][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (wave == 0 && col < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += part[w][lane];
+    out[col] = beta != 0.f ? beta * out[col] + t : t;
   }
 }
 
@@ -296,6 +328,15 @@ __global__ void relu_dropout_bwd_kernel(const float* __restrict__ y, float* __re
   for (; i < n; i += stride) dy[i] = y[i] > 0.f ? dy[i] * scale : 0.f;
 }
 
+// C[M,N] += X[M,N] (row-major with leading dimensions): the unfused form of isic_gemm_f32_add_ws's addend
+__global__ void add2d_kernel(float* __restrict__ C, int ldc, const float* __restrict__ X, int ldx, int M, int N) {
+  const int64_t n = (int64_t)M * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / N, c = i - r * N;
+    C[r * ldc + c] += X[r * ldx + c];
+  }
+}
+
 // up to 32 (dst, src, count) segments in one launch: blockIdx.y = segment
 struct MultiCopyArgs { float* dst[32]; const float* src[32]; long long count[32]; int accumulate; };
 __global__ __launch_bounds__(256) void multi_copy_kernel(MultiCopyArgs a) {
@@ -312,9 +353,12 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(MultiCopyArgs a) {
 inline int small_split_plan(int M, int N, int K, bool plain, int* klen) {
   *klen = ((K + BK - 1) / BK) * BK;
   const long long tiles = (long long)ceil_div(M, BM) * ceil_div(N, BN);
-  if (!plain || K < 2048 || tiles >= 512) return 1;
+  // (a handful of tiles walking even 256 k is latency-bound -- 16 K-tiles of two barriers and an exposed global load each:
+  //  22-25 us for the classifier's dW = dY^T X over a 256-graph batch; 64 k per split brings it to the launch floor)
+  const bool tiny = plain && tiles <= 8 && K >= 256 && K < 2048;
+  if (!plain || (K < 2048 && !tiny) || tiles >= 512) return 1;
   long long want = (1024 + tiles - 1) / tiles;                     // ~4 blocks per CU
-  const long long max_split = K / 256;                             // at least 256 k per split
+  const long long max_split = tiny ? K / 64 : K / 256;             // at least 256 (64) k per split
   if (want > max_split) want = max_split;
   if (want <= 1) return 1;
   *klen = (int)(((K + want - 1) / want + BK - 1) / BK) * BK;
@@ -360,10 +404,28 @@ int isic_gemm_f32_ws(int transA, int transB, int M, int N, int K, const float* A
                                     workspace_bytes, stream);
 }
 
+int isic_gemm_f32_add_ws(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                         float* C, int ldc, const float* bias, int act, float beta, const float* addend, int ldadd,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  if (!addend)
+    return isic_gemm_f32_ws(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, beta, workspace, workspace_bytes, stream);
+  ISIC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && ldadd >= N);
+  if (M == 0 || N == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(A && B && C);
+  ISIC_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N);
+  ISIC_CHECK_ARG(act >= ISIC_ACT_NONE && act <= ISIC_ACT_TANH);
+  int rc = isic_gemm_f32r_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, beta, addend, ldadd, as_stream(stream));
+  if (rc != ISIC_ERR_UNSUPPORTED) return rc;             // the row-panel kernel adds it in its epilogue
+  rc = isic_gemm_f32_ws(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, beta, workspace, workspace_bytes, stream);
+  if (rc != ISIC_OK) return rc;
+  hipLaunchKernelGGL(add2d_kernel, dim3(grid_for((int64_t)M * N, 256)), dim3(256), 0, as_stream(stream), C, ldc, addend, ldadd, M, N);
+  return isic_launch_status();
+}
+
 int isic_test_gemm_f32_variant(int variant, int transA, int transB, int M, int N, int K, const float* A, int lda,
                                const float* B, int ldb, float* C, int ldc, const float* bias, int act, float beta,
                                void* workspace, size_t workspace_bytes, void* stream) {
-  ISIC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && variant >= 0 && variant <= 3);
+  ISIC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && variant >= 0 && variant <= 4);
   if (M == 0 || N == 0) return ISIC_OK;
   ISIC_CHECK_ARG(A && B && C);
   ISIC_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N);
@@ -373,7 +435,12 @@ int isic_test_gemm_f32_variant(int variant, int transA, int transB, int M, int N
                                          workspace_bytes, variant == 3, as_stream(stream));
     if (rc != ISIC_ERR_UNSUPPORTED || variant == 3) return rc;
   }
-  if (variant != 1) {
+  if (variant == 0 || variant == 4) {
+    const int rc = isic_gemm_f32r_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, beta, nullptr, 0,
+                                         as_stream(stream));
+    if (rc != ISIC_ERR_UNSUPPORTED || variant == 4) return rc;
+  }
+  if (variant != 1 && variant != 4) {
     const int rc = isic_gemm_f32p_launch(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, beta, workspace,
                                          workspace_bytes, as_stream(stream));
     if (rc != ISIC_ERR_UNSUPPORTED || variant == 2) return rc;   // launched (or failed for real): large, 16-byte friendly products
@@ -468,6 +535,10 @@ int isic_colsum_f32_ws(const float* X, int M, int N, int ldx, float* out, float 
   }
   const int rows_per_block = ceil_div(M > 0 ? M : 1, chunks);
   chunks = ceil_div(M > 0 ? M : 1, rows_per_block);
+  if (chunks == 1) {
+    hipLaunchKernelGGL(colsum_small_kernel, dim3(colblocks), dim3(1024), 0, as_stream(stream), X, M, N, ldx, out, beta);
+    return isic_launch_status();
+  }
   if (chunks > 1)
     hipLaunchKernelGGL(gemm_scale_kernel, dim3(1), dim3(256), 0, as_stream(stream), out, 1, N, N, beta);
   hipLaunchKernelGGL(colsum_kernel, dim3(colblocks, chunks), dim3(256), 0, as_stream(stream), X, M, N, ldx, out, beta,

@@ -57,7 +57,7 @@ __device__ __forceinline__ void g32_glds16(const void* gsrc, unsigned lds_dst) {
 }
 
 __device__ __forceinline__ float g32_act(float v, int act) {
-  return act == ISIC_ACT_RELU ? fmaxf(v, 0.f) : (act == ISIC_ACT_TANH ? tanhf(v) : v);
+  return act == ISIC_ACT_RELU ? fmaxf(v, 0.f) : (act == ISIC_ACT_TANH ? isic_tanhf(v) : v);
 }
 
 template <bool AK, bool BK>

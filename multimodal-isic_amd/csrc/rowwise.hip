@@ -104,17 +104,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
 }
 
 // dgamma[n] += sum over the blocks' partial rows (and dbeta likewise), in block order: 16 lanes per column, fixed xor tree
+// (dxsum != NULL: a third row per block, the column sums of dx -- the bias gradient of the layer below)
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int N,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             float* __restrict__ dxsum) {
   const int g = threadIdx.x & 15;
-  const int n = blockIdx.x * 16 + (threadIdx.x >> 4);        // 0 .. 2N-1: dgamma columns, then dbeta columns
+  const int nv = dxsum ? 3 : 2;
+  const int n = blockIdx.x * 16 + (threadIdx.x >> 4);        // 0 .. nv*N-1: dgamma columns, then dbeta columns (, then dx sums)
   float s = 0.f;
-  if (n < 2 * N)
-    for (int b = g; b < nblocks; b += 16) s += partial[(size_t)b * 2 * N + n];
+  if (n < nv * N)
+    for (int b = g; b < nblocks; b += 16) s += partial[(size_t)b * nv * N + n];
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
-  if (n < 2 * N && g == 0) {
-    if (n < N) dgamma[n] += s; else dbeta[n - N] += s;
+  if (n < nv * N && g == 0) {
+    if (n < N) dgamma[n] += s; else if (n < 2 * N) dbeta[n - N] += s; else dxsum[n - 2 * N] += s;
   }
 }
 
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(
 
 // 1024-thread blocks, one per CU at most: the dgamma / dbeta atomics of all blocks hit the same 2 N addresses and retire
 // at ~3 ns each per cache line (1568 blocks of 256 threads: 160 us, all atomics), so there are few, fat blocks.
-template <int LPR>
+template <int LPR, bool DXS>
 __global__ __launch_bounds__(1024) void layernorm_bwd_vec_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
@@ -182,11 +185,11 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_vec_kernel(
     unsigned int thr, float scale, unsigned long long seed, unsigned long long stream_id,
     const unsigned long long* __restrict__ clock, float* __restrict__ partial) {
   if (clock) stream_id += clock[0] * 1024ULL;        // device step clock (captured graphs): stream = base + step * 1024
-  constexpr int RPW = 64 / LPR, N = 4 * LPR;
-  __shared__ f32x4 red[2][1024];
+  constexpr int RPW = 64 / LPR, N = 4 * LPR, NV = DXS ? 3 : 2;
+  __shared__ f32x4 red[NV][1024];
   const int lane = threadIdx.x & 63, sub = lane / LPR, col = (lane % LPR) * 4;
   const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + col), b4 = *reinterpret_cast<const f32x4*>(beta + col);
-  f32x4 pg = {0.f, 0.f, 0.f, 0.f}, pb = pg;
+  f32x4 pg = {0.f, 0.f, 0.f, 0.f}, pb = pg, pd = pg;
   const int stride = gridDim.x * 16 * RPW;
   for (int base = (blockIdx.x * 16 + (threadIdx.x >> 6)) * RPW; base < M; base += stride) {
     const bool valid = base + sub < M;
@@ -214,18 +217,25 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_vec_kernel(
     const float s1 = group_sum<LPR>((g[0] + g[1]) + (g[2] + g[3])) * (1.f / N);
     const f32x4 gx = g * xh;
     const float s2 = group_sum<LPR>((gx[0] + gx[1]) + (gx[2] + gx[3])) * (1.f / N);
-    if (valid) *reinterpret_cast<f32x4*>(dx + idx) = (g - s1 - xh * s2) * rstd;
+    const f32x4 dxv = (g - s1 - xh * s2) * rstd;
+    if (valid) *reinterpret_cast<f32x4*>(dx + idx) = dxv;
+    if (DXS && valid) pd += dxv;
   }
   red[0][threadIdx.x] = pg;
   red[1][threadIdx.x] = pb;
+  if (DXS) red[NV - 1][threadIdx.x] = pd;
   __syncthreads();
   if (threadIdx.x < LPR) {                     // the 16 waves x RPW row slots that hold the same columns
-    f32x4 tg = {0.f, 0.f, 0.f, 0.f}, tb = tg;
+    f32x4 tg = {0.f, 0.f, 0.f, 0.f}, tb = tg, td = tg;
 #pragma unroll
-    for (int k = 0; k < 16 * RPW; ++k) { tg += red[0][k * LPR + threadIdx.x]; tb += red[1][k * LPR + threadIdx.x]; }
-    if (partial) {                                   // deterministic: the block's own row of [2][N]
-      *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.x * 2 * N + threadIdx.x * 4) = tg;
-      *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.x * 2 * N + N + threadIdx.x * 4) = tb;
+    for (int k = 0; k < 16 * RPW; ++k) {
+      tg += red[0][k * LPR + threadIdx.x]; tb += red[1][k * LPR + threadIdx.x];
+      if (DXS) td += red[NV - 1][k * LPR + threadIdx.x];
+    }
+    if (partial) {                                   // deterministic: the block's own row of [NV][N]
+      *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.x * NV * N + threadIdx.x * 4) = tg;
+      *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.x * NV * N + N + threadIdx.x * 4) = tb;
+      if (DXS) *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.x * NV * N + 2 * N + threadIdx.x * 4) = td;
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -413,13 +423,21 @@ int isic_layernorm_bwd_clk(const float* dy, const float* x, const float* gamma, 
 }
 
 size_t isic_layernorm_bwd_workspace_bytes(int N) {
-  return N > 0 && N <= 1024 ? (size_t)1024 * 2 * N * sizeof(float) : 0;      // at most 1024 blocks, a [2][N] row each
+  return N > 0 && N <= 1024 ? (size_t)1024 * 3 * N * sizeof(float) : 0;      // at most 1024 blocks, a [3][N] row each
 }
 
 int isic_layernorm_bwd_ws(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
                           const float* rstd, float* dx, float* dgamma, float* dbeta, int M, int N, int relu,
                           uint32_t drop_threshold, float drop_scale, uint64_t seed, uint64_t stream_id,
                           const uint64_t* clock, void* workspace, size_t workspace_bytes, void* stream) {
+  return isic_layernorm_bwd_dxsum_ws(dy, x, gamma, beta, mean, rstd, dx, dgamma, dbeta, nullptr, M, N, relu, drop_threshold,
+                                     drop_scale, seed, stream_id, clock, workspace, workspace_bytes, stream);
+}
+
+int isic_layernorm_bwd_dxsum_ws(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
+                                const float* rstd, float* dx, float* dgamma, float* dbeta, float* dxsum, int M, int N,
+                                int relu, uint32_t drop_threshold, float drop_scale, uint64_t seed, uint64_t stream_id,
+                                const uint64_t* clock, void* workspace, size_t workspace_bytes, void* stream) {
   ISIC_CHECK_ARG(M >= 0 && N > 0);
   if (M == 0) return ISIC_OK;
   ISIC_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && dgamma && dbeta);
@@ -434,17 +452,20 @@ int isic_layernorm_bwd_ws(const float* dy, const float* x, const float* gamma, c
     const int rpw = 256 / N;
     int gridv = ceil_div(M, 16 * rpw * 4);                         // >= 4 passes per wave
     if (gridv > 192) gridv = 192;                                  // few fat blocks: see layernorm_bwd_vec_kernel
-#define LAUNCH_LNB(LPR)                                                                                             \
-  hipLaunchKernelGGL(layernorm_bwd_vec_kernel<LPR>, dim3(gridv), dim3(1024), 0, as_stream(stream), dy, x, gamma, beta, mean, \
+    if (dxsum && !partial) return ISIC_ERR_WORKSPACE;              // the column sums of dx exist in the order-fixed form only
+#define LAUNCH_LNB(LPR, DXS)                                                                                             \
+  hipLaunchKernelGGL((layernorm_bwd_vec_kernel<LPR, DXS>), dim3(gridv), dim3(1024), 0, as_stream(stream), dy, x, gamma, beta, mean, \
                      rstd, dx, dgamma, dbeta, M, relu, drop_threshold, drop_scale, (unsigned long long)seed,        \
                      (unsigned long long)stream_id, (const unsigned long long*)clock, partial)
-    if (N == 64) LAUNCH_LNB(16); else if (N == 128) LAUNCH_LNB(32); else LAUNCH_LNB(64);
+    if (dxsum) { if (N == 64) LAUNCH_LNB(16, true); else if (N == 128) LAUNCH_LNB(32, true); else LAUNCH_LNB(64, true); }
+    else { if (N == 64) LAUNCH_LNB(16, false); else if (N == 128) LAUNCH_LNB(32, false); else LAUNCH_LNB(64, false); }
 #undef LAUNCH_LNB
     if (partial)
-      hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(2 * N, 16)), dim3(256), 0, as_stream(stream), partial, gridv, N,
-                         dgamma, dbeta);
+      hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div((dxsum ? 3 : 2) * N, 16)), dim3(256), 0, as_stream(stream), partial,
+                         gridv, N, dgamma, dbeta, dxsum);
     return isic_launch_status();
   }
+  if (dxsum) return ISIC_ERR_UNSUPPORTED;                          // N in {64, 128, 256}, 16-byte aligned rows only
   int grid = ceil_div(M, 4 * 8);  // >= 8 rows per wave amortise the atomics
   if (grid > 1024) grid = 1024;
   if (grid < 1) grid = 1;
@@ -459,7 +480,7 @@ int isic_layernorm_bwd_ws(const float* dy, const float* x, const float* gamma, c
 #undef LAUNCH_LN
   if (partial)
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(2 * N, 16)), dim3(256), 0, as_stream(stream), partial, grid, N,
-                       dgamma, dbeta);
+                       dgamma, dbeta, (float*)nullptr);
   return isic_launch_status();
 }
 

@@ -30,7 +30,7 @@ import torch.nn as nn
 
 from isic_hip import ops
 from isic_hip.bags import BagOffsets, as_offsets
-from isic_hip.graph import (GraphBatch, fa_conv, gat_conv, gatv2_conv, l2_normalize, spmm,
+from isic_hip.graph import (GraphBatch, fa_conv, gat_conv, gatv2_conv, gcn_block, l2_normalize, spmm,
                             transformer_attention)
 from utils_g_mil import _DropoutClock
 
@@ -244,6 +244,12 @@ class GraphMIL(nn.Module):
         p_drop = self.gnn_dropout.p
         for i, layer in enumerate(self.gnn_layers):
             h_prev = h
+            if self.gnn_type == 'gcn' and self.use_layer_norm and self.use_residual and layer.lin.weight.shape[0] == h.shape[1]:
+                # the reference's default layer (05:184-199) as one autograd node: the residual's and the convolution's
+                # gradients into h meet in the data-gradient GEMM's epilogue
+                ln = self.layer_norms[i]
+                h = gcn_block(h, layer.lin.weight, layer.bias, ln.weight, ln.bias, g, ln.eps, clk.spec(p_drop, i, tr), True)
+                continue
             if self.gnn_type == 'mlp':
                 h = ops.linear(h, layer[0].weight, layer[0].bias)
             elif self.gnn_type == 'gcn':

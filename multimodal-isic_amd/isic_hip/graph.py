@@ -6,7 +6,7 @@ import torch
 
 from .bags import BagOffsets
 from .lib import IsicHipError, call
-from .ops import _chk, _f32c, colsum
+from .ops import _acc_target, _chk, _f32c, colsum
 
 
 def knn_indices(x, offsets: BagOffsets, k, return_dist=False):
@@ -99,6 +99,7 @@ class SpmmFn(torch.autograd.Function):
                      _f32c(addend) if addend is not None else None, float(addend_scale))
         ctx.graph, ctx.alpha, ctx.addend_scale = graph, float(alpha), float(addend_scale)
         ctx.has_bias, ctx.has_addend = bias is not None, addend is not None
+        ctx.bias_param = bias                   # the Parameter itself: fused_grad_accumulation adds into its .grad
         return out
 
     @staticmethod
@@ -110,7 +111,11 @@ class SpmmFn(torch.autograd.Function):
             dx = torch.empty_like(dy)
             _spmm_launch(g, True, dy, None, dx, ctx.alpha, None, 0.0)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dy)
+            tgt = _acc_target(ctx.bias_param)
+            if tgt is not None:
+                colsum(dy, out=tgt, beta=1.0)
+            else:
+                db = colsum(dy)
         if ctx.has_addend and ctx.needs_input_grad[4]:
             da = dy * ctx.addend_scale
         return dx, None, db, None, da, None
@@ -118,6 +123,92 @@ class SpmmFn(torch.autograd.Function):
 
 def spmm(x, graph, bias=None, alpha=1.0, addend=None, addend_scale=0.0):
     return SpmmFn.apply(x, graph, bias, alpha, addend, addend_scale)
+
+
+class GcnBlockFn(torch.autograd.Function):
+    """One residual GCN layer of GraphMIL as ONE autograd node (`05_train_gnns.py:184-199`):
+
+        y = dropout(relu(LayerNorm(A^ (h W^T) + b))) + h
+
+    The kernels are those of ``ops.linear`` -> ``spmm`` -> ``ops.layer_norm``; what the single node buys is the backward: the
+    two gradient paths into ``h`` (the residual's dy and the convolution's (A^T d) W) meet in the epilogue of the data-gradient
+    GEMM (``gemm(..., addend=dy)``) instead of in an elementwise pass autograd would launch over both [T, F] tensors."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, gamma, beta, graph, eps, drop, residual):
+        from .ops import NO_DROP, gemm
+        _chk(h, weight, bias, gamma, beta)
+        h2, w = _f32c(h), _f32c(weight)
+        n, F = h2.shape[0], w.shape[0]
+        if n != graph.n_nodes:
+            raise ValueError(f"x has {n} rows, graph has {graph.n_nodes} nodes")
+        if residual and w.shape[1] != F:
+            raise ValueError("a residual GCN block keeps the feature width")
+        drop = drop or NO_DROP
+        lin = gemm(h2, w, trans_b=True)
+        agg = torch.empty_like(lin)
+        _spmm_launch(graph, False, lin, _f32c(bias) if bias is not None else None, agg, 1.0, None, 0.0)
+        g_, b_ = _f32c(gamma), _f32c(beta)
+        y = torch.empty_like(agg)
+        mean = torch.empty((n,), device=h2.device, dtype=torch.float32)
+        rstd = torch.empty((n,), device=h2.device, dtype=torch.float32)
+        call("isic_layernorm_fwd_clk", agg, g_, b_, h2 if residual else None, y, mean, rstd, n, F, float(eps), 1, drop.threshold,
+             drop.scale, drop.seed, drop.stream, drop.clock)
+        ctx.graph, ctx.drop, ctx.residual = graph, drop, bool(residual)
+        ctx.params = (weight, bias, gamma, beta)
+        ctx.save_for_backward(h2, w, agg, g_, b_, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .ops import _workspace, gemm
+        h2, w, agg, g_, b_, mean, rstd = ctx.saved_tensors
+        weight, bias, gamma, beta = ctx.params
+        drop = ctx.drop
+        n, F = agg.shape
+        dy2 = _f32c(dy)
+        # LayerNorm (+ReLU +dropout) backward; dgamma / dbeta accumulate
+        d_agg = torch.empty_like(agg)
+        tg, tb = _acc_target(gamma), _acc_target(beta)
+        fused_ln = tg is not None and tb is not None
+        dg = tg if fused_ln else torch.zeros((F,), device=agg.device, dtype=torch.float32)
+        db_ln = tb if fused_ln else torch.zeros((F,), device=agg.device, dtype=torch.float32)
+        ws = _workspace(call("isic_layernorm_bwd_workspace_bytes", F), agg.device)
+        # GCNConv's bias gradient = column sums of d_agg: taken by the LayerNorm backward itself for the vector widths
+        dbias, want_db = None, bias is not None and ctx.needs_input_grad[2]
+        if want_db and F in (64, 128, 256):
+            t = _acc_target(bias)
+            if t is None:
+                t = dbias = torch.zeros((F,), device=agg.device, dtype=torch.float32)
+            call("isic_layernorm_bwd_dxsum_ws", dy2, agg, g_, b_, mean, rstd, d_agg, dg, db_ln, t, n, F, 1, drop.threshold,
+                 drop.scale, drop.seed, drop.stream, drop.clock, ws, ws.numel() if ws is not None else 0)
+            want_db = False
+        else:
+            call("isic_layernorm_bwd_ws", dy2, agg, g_, b_, mean, rstd, d_agg, dg, db_ln, n, F, 1, drop.threshold, drop.scale,
+                 drop.seed, drop.stream, drop.clock, ws, ws.numel() if ws is not None else 0)
+        if want_db:
+            t = _acc_target(bias)
+            if t is not None:
+                colsum(d_agg, out=t, beta=1.0)
+            else:
+                dbias = colsum(d_agg)
+        d_lin = torch.empty_like(d_agg)
+        _spmm_launch(ctx.graph, True, d_agg, None, d_lin, 1.0, None, 0.0)
+        dW = None
+        if ctx.needs_input_grad[1]:
+            t = _acc_target(weight)
+            if t is not None:
+                gemm(d_lin, h2, trans_a=True, out=t, beta=1.0)
+            else:
+                dW = gemm(d_lin, h2, trans_a=True)
+        dh = None
+        if ctx.needs_input_grad[0]:
+            dh = gemm(d_lin, w, addend=dy2 if ctx.residual else None)      # (A^T d) W + dy: both paths in one epilogue
+        return dh, dW, dbias, (None if fused_ln else dg), (None if fused_ln else db_ln), None, None, None, None
+
+
+def gcn_block(h, weight, bias, gamma, beta, graph, eps=1e-5, drop=None, residual=True):
+    return GcnBlockFn.apply(h, weight, bias, gamma, beta, graph, eps, drop, residual)
 
 
 class L2NormalizeFn(torch.autograd.Function):

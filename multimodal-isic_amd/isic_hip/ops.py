@@ -96,8 +96,8 @@ def _acc_target(p):
 
 
 # --------------------------------------------------------------------------- raw helpers (no autograd)
-def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, out=None, beta=0.0):
-    """out[M,N] = act(op(a) @ op(b) + bias) + beta*out   (fp32 MFMA)."""
+def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, out=None, beta=0.0, addend=None):
+    """out[M,N] = act(op(a) @ op(b) + bias) + beta*out (+ addend)   (fp32 MFMA)."""
     M = a.shape[1] if trans_a else a.shape[0]
     K = a.shape[0] if trans_a else a.shape[1]
     N = b.shape[0] if trans_b else b.shape[1]
@@ -110,6 +110,13 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, out=None, 
         if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1) or not t.is_cuda or t.dtype != torch.float32:
             raise IsicHipError("gemm operands must be 2-D fp32 device tensors with unit inner stride")
     ws = _workspace(call("isic_gemm_f32_workspace_bytes", int(trans_a), int(trans_b), M, N, K), a.device)
+    if addend is not None:
+        if addend.shape != out.shape or addend.dtype != torch.float32 or not addend.is_cuda or (N > 1 and addend.stride(1) != 1):
+            raise IsicHipError("gemm addend must be an fp32 device tensor of the output's shape with unit inner stride")
+        call("isic_gemm_f32_add_ws", int(trans_a), int(trans_b), M, N, K, a.data_ptr(), max(a.stride(0), a.shape[1]),
+             b.data_ptr(), max(b.stride(0), b.shape[1]), out.data_ptr(), max(out.stride(0), out.shape[1]), bias, act,
+             float(beta), addend.data_ptr(), max(addend.stride(0), N), ws, ws.numel() if ws is not None else 0)
+        return out
     call("isic_gemm_f32_ws", int(trans_a), int(trans_b), M, N, K, a.data_ptr(), max(a.stride(0), a.shape[1]), b.data_ptr(),
          max(b.stride(0), b.shape[1]), out.data_ptr(), max(out.stride(0), out.shape[1]), bias, act, float(beta),
          ws, ws.numel() if ws is not None else 0)

@@ -161,13 +161,21 @@ PGEMM_CASES = [
     (3004, 260, 2052, False, False, False, 0),     # ragged, k contiguous x k strided
     (1100, 520, 4100, True, True, True, 0),        # k strided x k contiguous with a bias (un-swapped)
     (260, 1028, 8200, True, False, False, 0),      # k strided x k strided, split-K, ragged
+    # the row-panel kernel (gemm_f32r.hip: long M, K <= 128, weights resident in LDS) ...
+    (30003, 192, 64, False, True, True, 1),        # ragged rows, a 128 + 64 column split, K = 64
+    (20000, 64, 128, False, False, False, 0),      # one 64-column half, weights given [K][N]
+    (4100, 128, 48, False, True, False, 2),        # K = 48
+    # ... and the register-fed A^T B split-K kernel (gemm_f32t.hip: small output, long reduction)
+    (64, 128, 50173, True, False, False, 0),       # K not a multiple of 4, a 64-row output
+    (128, 256, 9001, True, False, False, 0),       # two column tiles
 ]
 
 
 @pytest.mark.parametrize("case", PGEMM_CASES, ids=[f"{c[0]}x{c[1]}x{c[2]}{'T' if c[3] else 'N'}{'T' if c[4] else 'N'}" for c in PGEMM_CASES])
 @pytest.mark.parametrize("beta", [0.0, 1.0])
 def test_persistent_fp32_gemm(case, beta):
-    """`isic_gemm_f32_ws` on the shapes that take the persistent 256 x 128 x 32 kernel: against an fp64 product (exact-fp32
+    """`isic_gemm_f32_ws` on the shapes that take the persistent 256 x 128 x 32 kernel, the row-panel kernel or the
+    register-fed A^T B kernel: against an fp64 product (exact-fp32
     MFMA: only the summation order differs, 2e-6 of the output scale per 1000 k), bit-identical between two runs (split-K
     partials are added in split order: no atomics), and with padded leading dimensions."""
     from isic_hip import ops

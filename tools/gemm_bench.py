@@ -27,6 +27,9 @@ SHAPES = [  # (name, M, N, K, transA, transB, bias)
     ("gcn lin dW      dY^T X", 128, 128, 50176, 1, 0, 0),
     ("att heads dW    dY^T X", 512, 128, 50176, 1, 0, 0),
     ("mil head fwd", 2048, 128, 512, 0, 1, 1),
+    ("(scaling) 4 x rows", 200704, 128, 128, 0, 1, 0),
+    ("(scaling) rows / 4", 12544, 128, 128, 0, 1, 0),
+    ("(scaling) dW 4 x K", 128, 128, 200704, 1, 0, 0),
 ]
 
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 kernel statistics of the graph-path bench step, eager launch (run on the GPU box from the repo root).
+# rocprofv3 kernel statistics of the graph-path bench step as bench.py runs it (hipGraph replay) (run on the GPU box from the repo root).
 # Output: gpurun_out/prof_gnn/r03_gnn_bench_kernel_stats.csv (copy to profiles/).
 set -e
 R=$PWD
@@ -7,7 +7,7 @@ mkdir -p $R/gpurun_out/prof_gnn
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_gnn/run
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_gnn/run -- \
-  python3 $R/bench.py --config gnn --steps 30 --warmup 5 --no-cpu-baseline --no-graph > $R/gpurun_out/prof_gnn/bench.json 2> $R/gpurun_out/prof_gnn/bench.err
+  python3 $R/bench.py --config gnn --steps 30 --warmup 5 --no-cpu-baseline > $R/gpurun_out/prof_gnn/bench.json 2> $R/gpurun_out/prof_gnn/bench.err
 f=$(ls $R/gpurun_out/prof_gnn/run/*/*kernel_stats.csv | head -1)
 cp $f $R/gpurun_out/prof_gnn/r03_gnn_bench_kernel_stats.csv
 python3 - <<PY
