@@ -110,21 +110,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
     lstore();
     __syncthreads();
     if (kt + 1 < nk) gload(kt + 1);
-    float4 af[2], bf[2];
+    f32x4 af[2], bf[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      af[i] = *reinterpret_cast<const float4*>(&As[(wm * 32 + i * 16 + fr) * LDT + 4 * fg]);
-      bf[i] = *reinterpret_cast<const float4*>(&Bs[(wn * 32 + i * 16 + fr) * LDT + 4 * fg]);
+      af[i] = *reinterpret_cast<const f32x4*>(&As[(wm * 32 + i * 16 + fr) * LDT + 4 * fg]);
+      bf[i] = *reinterpret_cast<const f32x4*>(&Bs[(wn * 32 + i * 16 + fr) * LDT + 4 * fg]);
     }
+    // k-step outermost: consecutive MFMAs write different accumulators (a dependent one issues ~6 slots late)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-      }
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
   }
 
   // epilogue: C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg

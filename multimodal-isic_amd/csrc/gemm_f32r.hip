@@ -7,8 +7,8 @@
 // MFMA) and a tiled kernel spends a third of its time filling its operand ring per tile and on 256-row tiles that do not
 // divide the rows over 256 CUs (196 tiles).  Here:
 //   * the WHOLE weight slice (128 output columns x K) sits in LDS for the life of the block, transposed / permuted once;
-//   * the unit of work is a 16-row panel x 64 columns: 12,544 / 6,272 units for 4 x 256 SIMDs (>= 94 % balanced), dealt
-//     block-major so that a remainder spreads over the CUs;
+//   * the unit of work is a 16-row panel x 64 columns, panels dealt round-robin to the CUs and a CU's units round-robin to its
+//     8 waves: 24.5 units per CU for 4 SIMDs at 50,176 rows (87 % balanced), both halves of a panel on the same CU;
 //   * A goes global -> registers, no LDS: lane (i = l & 15, q = l >> 4) loads float4 A[r0 + i][16 c + 4 q ..+3], which is
 //     the A operand of four consecutive MFMA k-steps (any order of k is a valid summation order as long as B follows it);
 //     the next unit's panel is in flight while this one multiplies;
@@ -32,15 +32,24 @@ struct RpArgs {
   int panels;                            // ceil(M / 16)
 };
 
-template <int KC>                        // KC = K / 16 chunks of 16 k
+// 16-byte global load OUTSIDE hipcc's vmcnt bookkeeping: the compiler's s_waitcnt insertion is conservative across the
+// back-edge of the unit loop -- it waited for the panel it had just requested (vmcnt(0) in front of the first MFMA) and for
+// every store's round trip before the next one (tests with the loads / stores compiled out: 14 us each of an 84 us launch,
+// none of it overlapped).  The waves count by hand instead: rp_wait<N>() = "all but the N youngest requests have landed".
+__device__ __forceinline__ f32x4 rp_gload16(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+template <int KC, bool ADD>              // KC = K / 16 chunks of 16 k; ADD: an addend[M][ldadd] joins in the epilogue
 __global__ __launch_bounds__(RP_WAVES * 64) void gemm_rowpanel_kernel(RpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wt[];         // [128 permuted columns][K + 4]
   const int K = KC * 16, PITCH = K + 4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
-  const int grid = gridDim.x, waves_all = grid * RP_WAVES;
-  const int widx = wave * grid + blockIdx.x;                         // block-major deal: a remainder spreads over the CUs
+  const int grid = gridDim.x;
 
   for (int n0 = 0; n0 < a.N; n0 += RP_SLICE) {
     const int width = min(RP_SLICE, a.N - n0);                       // 128 or 64
@@ -65,30 +74,68 @@ __global__ __launch_bounds__(RP_WAVES * 64) void gemm_rowpanel_kernel(RpArgs a) 
         }
       }
     }
+    // the bias of the wave's two possible column groups (compiler-tracked loads: waited for here, once per slice)
+    f32x4 bias2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (a.bias) {
+      bias2[0] = *reinterpret_cast<const f32x4*>(a.bias + n0 + 4 * li);
+      if (halves == 2) bias2[1] = *reinterpret_cast<const f32x4*>(a.bias + n0 + 64 + 4 * li);
+    }
     __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the hand count below starts from zero
 
-    const int units = a.panels * halves;
-    f32x4 an[KC];                                                    // the next unit's A panel
-    auto load_panel = [&](int u) {
-      const int p = halves == 2 ? (u >> 1) : u;
-      const int r = p * 16 + li;
-      const bool ok = u < units && r < a.M;
-      const float* src = a.A + (size_t)(ok ? r : 0) * a.lda + 4 * lq;
+    // Panels are dealt to the blocks round-robin (panel p -> block p % grid); a block walks the units of ITS panels -- the two
+    // 64-column halves of a panel are consecutive units, i.e. two neighbouring waves of the same CU in the same round.
+    const int my_panels = (a.panels - (int)blockIdx.x + grid - 1) / grid;          // panels blockIdx.x, + grid, ...
+    const int units = my_panels * halves;
+    f32x4 an[KC], dn[4];                                             // the next unit's A panel (and addend rows)
 #pragma unroll
-      for (int c = 0; c < KC; ++c) an[c] = ok ? *reinterpret_cast<const f32x4*>(src + 16 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int v = 0; v < 4; ++v) dn[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // requests of unit j: KC panel loads (+ 4 addend loads): rows past M are clamped (loaded, never stored)
+    auto request = [&](int j) {
+      const int p = (int)blockIdx.x + (halves == 2 ? (j >> 1) : j) * grid;
+      const int r = min(p * 16 + li, a.M - 1);
+      const float* src = a.A + (size_t)r * a.lda + 4 * lq;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) an[c] = rp_gload16(src + 16 * c);
+      if (ADD) {
+        const int col = n0 + (halves == 2 ? (j & 1) : 0) * 64 + 4 * li;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) dn[v] = rp_gload16(a.addend + (size_t)min(p * 16 + 4 * lq + v, a.M - 1) * a.ldadd + col);
+      }
     };
-    int u = widx;
-    load_panel(u);
-    for (; u < units; u += waves_all) {
-      f32x4 af[KC];
+    // A requested register may only be touched after its wait -- and the compiler moves loop-carried values around at the END
+    // of a loop body (phi copies).  So the wait for the NEXT unit's requests closes the iteration that issued them (they had
+    // the whole multiply phase to land), and what the loop carries is the landed value.
+    auto landed = [&](int allow4) {
+      if (allow4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but the four stores issued after the requests
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // (volatile asm keeps its order; the empty ones make every later use of a requested register depend on the wait)
+#pragma unroll
+      for (int c = 0; c < KC; ++c) asm volatile("" : "+v"(an[c]));
+      if (ADD) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) asm volatile("" : "+v"(dn[v]));
+      }
+    };
+    int u = wave;
+    if (u < units) { request(u); landed(0); }
+    for (; u < units; u += RP_WAVES) {
+      f32x4 af[KC], ad[4];
 #pragma unroll
       for (int c = 0; c < KC; ++c) af[c] = an[c];
-      load_panel(u + waves_all);
-      const int p = halves == 2 ? (u >> 1) : u, hf = halves == 2 ? (u & 1) : 0;
-      const float* wb = wt + (hf * 64 + li) * PITCH + 4 * lq;        // tile t: + 16 t rows
-      f32x4 acc[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int v = 0; v < 4; ++v) ad[v] = dn[v];
+      // (no branch around the requests -- a join would make the compiler copy the requested registers at once, before they
+      //  land: the last unit asks for itself again)
+      request(u + RP_WAVES < units ? u + RP_WAVES : u);
+      const int p = (int)blockIdx.x + (halves == 2 ? (u >> 1) : u) * grid, hf = halves == 2 ? (u & 1) : 0;
+      const float* wb = wt + (hf * 64 + li) * PITCH + 4 * lq;        // tile t: + 16 t rows
+      // TWO accumulators per column tile (even / odd k-steps), joined at the end: a v_mfma_f32_16x16x4_f32 can follow one that
+      // wrote the same accumulator only ~6 issue slots later (tests/probes/probe_mfma_f32.hip: 4 accumulators in the ring
+      // sustain 0.65 of the rate 16 do), and a unit has only four column tiles
+      f32x4 acc[4], acc2[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
       f32x4 bf[2][4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) bf[0][t] = *reinterpret_cast<const f32x4*>(wb + t * 16 * PITCH);
@@ -99,32 +146,50 @@ __global__ __launch_bounds__(RP_WAVES * 64) void gemm_rowpanel_kernel(RpArgs a) 
           for (int t = 0; t < 4; ++t) bf[(c + 1) & 1][t] = *reinterpret_cast<const f32x4*>(wb + t * 16 * PITCH + 16 * (c + 1));
         }
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
+        for (int x = 0; x < 4; x += 2) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c][x], bf[c & 1][t][x], acc[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c][x + 1], bf[c & 1][t][x + 1], acc2[t], 0, 0, 0);
+        }
       }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] += acc2[t];
       // acc[t][v] = C[16 p + 4 lq + v][n0 + 64 hf + 4 li + t]
       const int col = n0 + hf * 64 + 4 * li;
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + col);
+      const f32x4 bv = hf ? bias2[1] : bias2[0];
+      f32x4 o[4];
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const int row = p * 16 + 4 * lq + v;
-        if (row >= a.M) continue;
-        f32x4 o = {acc[0][v] + bv[0], acc[1][v] + bv[1], acc[2][v] + bv[2], acc[3][v] + bv[3]};
+        o[v] = (f32x4){acc[0][v] + bv[0], acc[1][v] + bv[1], acc[2][v] + bv[2], acc[3][v] + bv[3]};
         if (a.act == ISIC_ACT_RELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+          for (int e = 0; e < 4; ++e) o[v][e] = fmaxf(o[v][e], 0.f);
         } else if (a.act == ISIC_ACT_TANH) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = isic_tanhf(o[e]);
+          for (int e = 0; e < 4; ++e) o[v][e] = isic_tanhf(o[v][e]);
         }
-        f32x4* cp = reinterpret_cast<f32x4*>(a.C + (size_t)row * a.ldc + col);
-        if (a.beta != 0.f) o += a.beta * (*cp);
-        if (a.addend) o += *reinterpret_cast<const f32x4*>(a.addend + (size_t)row * a.ldadd + col);
-        *cp = o;
+        if (ADD) o[v] += ad[v];
+      }
+      float* crow = a.C + (size_t)(p * 16 + 4 * lq) * a.ldc + col;
+      if (p * 16 + 16 <= a.M && a.beta == 0.f) {                     // wave-uniform: a full panel, four stores, nothing to wait for
+#pragma unroll
+        for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(crow + (size_t)v * a.ldc) = o[v];
+        landed(1);
+      } else {                                                       // the last panel / beta: tracked loads, predicated stores
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          if (p * 16 + 4 * lq + v < a.M) {
+            f32x4* cp = reinterpret_cast<f32x4*>(crow + (size_t)v * a.ldc);
+            if (a.beta != 0.f) o[v] += a.beta * (*cp);
+            *cp = o[v];
+          }
+        }
+        landed(0);                                                   // unknown number of stores: drain everything
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // (requests never outlive the slice)
   }
 }
 
@@ -137,21 +202,20 @@ bool rp_ok(int transA, int M, int N, int K, int lda, int ldb, int ldc, const voi
   return (bits & 15) == 0;
 }
 
-template <int KC>
+template <int KC, bool ADD>
 int rp_launch(const RpArgs& a, hipStream_t stream) {
   const int lds = RP_SLICE * (KC * 16 + 4) * (int)sizeof(float);
   static IsicPerDeviceOnce once;              // hipFuncSetAttribute is per device (one flag set per template instance)
   if (lds > 48 * 1024 &&
       isic_once_per_device(once, [lds] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rowpanel_kernel<KC>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rowpanel_kernel<KC, ADD>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       }) != hipSuccess)
     return ISIC_ERR_LAUNCH;
   const int cus = isic_cu_count();
-  const int units = a.panels * (a.N >= RP_SLICE ? 2 : 1);
-  int grid = ceil_div(units, RP_WAVES);
+  int grid = ceil_div(a.panels * (a.N >= RP_SLICE ? 2 : 1), RP_WAVES);
   if (grid > cus) grid = cus;
-  hipLaunchKernelGGL(gemm_rowpanel_kernel<KC>, dim3(grid), dim3(RP_WAVES * 64), lds, stream, a);
+  hipLaunchKernelGGL((gemm_rowpanel_kernel<KC, ADD>), dim3(grid), dim3(RP_WAVES * 64), lds, stream, a);
   return isic_launch_status();
 }
 
@@ -167,14 +231,14 @@ int isic_gemm_f32r_launch(int transA, int transB, int M, int N, int K, const flo
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.transB = transB; a.act = act; a.beta = beta;
   a.panels = ceil_div(M, 16);
   switch (K / 16) {
-    case 1: return rp_launch<1>(a, stream);
-    case 2: return rp_launch<2>(a, stream);
-    case 3: return rp_launch<3>(a, stream);
-    case 4: return rp_launch<4>(a, stream);
-    case 5: return rp_launch<5>(a, stream);
-    case 6: return rp_launch<6>(a, stream);
-    case 7: return rp_launch<7>(a, stream);
-    case 8: return rp_launch<8>(a, stream);
+    case 1: return addend ? rp_launch<1, true>(a, stream) : rp_launch<1, false>(a, stream);
+    case 2: return addend ? rp_launch<2, true>(a, stream) : rp_launch<2, false>(a, stream);
+    case 3: return addend ? rp_launch<3, true>(a, stream) : rp_launch<3, false>(a, stream);
+    case 4: return addend ? rp_launch<4, true>(a, stream) : rp_launch<4, false>(a, stream);
+    case 5: return addend ? rp_launch<5, true>(a, stream) : rp_launch<5, false>(a, stream);
+    case 6: return addend ? rp_launch<6, true>(a, stream) : rp_launch<6, false>(a, stream);
+    case 7: return addend ? rp_launch<7, true>(a, stream) : rp_launch<7, false>(a, stream);
+    case 8: return addend ? rp_launch<8, true>(a, stream) : rp_launch<8, false>(a, stream);
   }
   return ISIC_ERR_UNSUPPORTED;
 }

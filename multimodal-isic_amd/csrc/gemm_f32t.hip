@@ -48,31 +48,47 @@ __global__ __launch_bounds__(512) void gemm_tn_skinny_kernel(TnArgs a) {
     for (int c = 0; c < 4; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   if (live) {
+    // The operand ring is requested with inline-asm loads hipcc does not track and counted by hand (as gemm_f32r.hip; its own
+    // s_waitcnt insertion drained the ring -- vmcnt(0) -- once per TP k-steps, right after a refill: half the launch).  A slot
+    // is requested 2 loads at a time, in order, so "slot p has landed" = at most 2 (TP - 1) younger requests in flight.
+    // Rows past K are clamped (finite values, multiplied by nothing: the loop stops at s_end; the ring's overrun is not used).
     const int kr = lane >> 4, c4 = (lane & 15) * 4;
     const float* pa = a.A + (size_t)m0 + c4;
     const float* pb = a.B + (size_t)n0 + c4;
     f32x4 fa[TP], fb[TP];
-    auto load = [&](int slot, int s) {                       // k-step s of this wave's K-group: rows 4 s .. 4 s + 3
-      const int k = 4 * s + kr;
-      const bool ok = s < s_end && k < a.K;
-      fa[slot] = ok ? *reinterpret_cast<const f32x4*>(pa + (size_t)k * a.lda) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      fb[slot] = ok ? *reinterpret_cast<const f32x4*>(pb + (size_t)k * a.ldb) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto request = [&](int slot, int s) {                    // k-step s of this wave's K-group: rows 4 s .. 4 s + 3
+      const int k = min(4 * s + kr, a.K - 1);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fa[slot]) : "v"(pa + (size_t)k * a.lda) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fb[slot]) : "v"(pb + (size_t)k * a.ldb) : "memory");
     };
+    const bool ktail = (a.K & 3) != 0;                       // the last k-step has rows past K: their products must not count
     int s = s_begin + kg;                                    // the two K-groups walk alternate k-steps
 #pragma unroll
-    for (int p = 0; p < TP; ++p) load(p, s + 2 * p);
+    for (int p = 0; p < TP; ++p) request(p, s + 2 * p);
     for (; s < s_end; s += 2 * TP) {
 #pragma unroll
       for (int p = 0; p < TP; ++p) {
-        if (s + 2 * p >= s_end) break;                       // wave-uniform: no multiplies on the zero-filled tail
-        const f32x4 va = fa[p], vb = fb[p];
-        load(p, s + 2 * (p + TP));                           // refill the slot: TP k-steps ahead
+        if (s + 2 * p >= s_end) break;                       // wave-uniform: no multiplies past the slab
+        // wait, THEN copy the slot out -- inside one asm statement: a tied in/out operand made the compiler copy the slot
+        // in front of the wait (operand set-up), i.e. before it had landed
+        f32x4 va, vb;
+        asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b64 %0, %2\n\tv_mov_b64 %1, %3"
+                     : "=&v"(*reinterpret_cast<unsigned long long*>(&va)), "=&v"(*(reinterpret_cast<unsigned long long*>(&va) + 1))
+                     : "v"(*reinterpret_cast<const unsigned long long*>(&fa[p])),
+                       "v"(*(reinterpret_cast<const unsigned long long*>(&fa[p]) + 1)), "n"(2 * (TP - 1)) : "memory");
+        asm volatile("v_mov_b64 %0, %2\n\tv_mov_b64 %1, %3"
+                     : "=&v"(*reinterpret_cast<unsigned long long*>(&vb)), "=&v"(*(reinterpret_cast<unsigned long long*>(&vb) + 1))
+                     : "v"(*reinterpret_cast<const unsigned long long*>(&fb[p])),
+                       "v"(*(reinterpret_cast<const unsigned long long*>(&fb[p]) + 1)) : "memory");
+        if (ktail && 4 * (s + 2 * p) + kr >= a.K) va = (f32x4){0.f, 0.f, 0.f, 0.f};       // (a clamped row is a repeated row)
+        request(p, s + 2 * (p + TP));                        // refill the slot: TP k-steps ahead
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int c = 0; c < 4; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[r], vb[c], acc[r][c], 0, 0, 0);
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the ring's overrun lands before the registers are reused
   }
 
   // join the two K-groups (fixed order: group 0 + group 1), then this slab's partial tile

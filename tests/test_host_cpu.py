@@ -298,3 +298,105 @@ def test_torch_library_ops_are_registered_with_fake_implementations():
         assert loss.shape == () and d.shape == (5, 4)
         assert O.gemm_f32(torch.empty(32, 10), torch.empty(8, 32), True, True, None, 0).shape == (10, 8)
     assert torch_ops.drop_args(None) == (0, 1.0, 0, 0)
+
+
+def _scan_requested_registers(name, body):
+    """Walk one kernel's gfx950 assembly with the in-order vmcnt model: every VMEM instruction joins a queue; `s_waitcnt
+    vmcnt(N)` retires all but the youngest N; an inline-asm global load's destination registers are 'requested' until the
+    load retires, and no other instruction may read or write them meanwhile.  A backward branch replays its loop body once
+    with the state at the branch (what the second iteration sees).  -> number of asm requests seen."""
+    import re
+    lines = [l.strip() for l in body.split("\n")]
+    labels = {l[:-1].split(":")[0]: i for i, l in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:", l)}
+    queue, requests, replayed = [], 0, set()
+
+    def regs_of(arg):
+        out = set()
+        for m in re.finditer(r"v\[(\d+):(\d+)\]|\bv(\d+)\b", arg):
+            out |= {int(m.group(3))} if m.group(3) else set(range(int(m.group(1)), int(m.group(2)) + 1))
+        return out
+
+    def run(lo, hi):
+        nonlocal requests
+        in_asm, i = False, lo
+        while i < hi:
+            t = lines[i]
+            i += 1
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if t.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if not t or t[0] in ";." or t.endswith(":"):
+                continue
+            op, _, rest = t.partition(" ")
+            rest = rest.split(";")[0]
+            m = re.search(r"vmcnt\((\d+)\)", t) if op == "s_waitcnt" else None
+            if m:
+                n = int(m.group(1))
+                del queue[:max(0, len(queue) - n)]
+                continue
+            pending = set().union(*[q for q in queue if q]) if queue else set()
+            parts = [x.strip() for x in rest.split(",")]
+            touched = regs_of(rest)
+            if op.startswith(("global_load", "global_store", "buffer_", "flat_", "scratch_")):
+                assert not (touched & pending), f"{name}: '{t}' touches a requested register before its wait"
+                if in_asm and op.startswith("global_load"):
+                    queue.append(regs_of(parts[0]))
+                    requests += 1
+                else:
+                    queue.append(None)
+                continue
+            assert not (touched & pending), f"{name}: '{t}' touches a requested register before its wait"
+            if op.startswith("s_cbranch") or op == "s_branch":
+                tgt = rest.strip()
+                if tgt in labels and labels[tgt] < i and (tgt, i) not in replayed:
+                    replayed.add((tgt, i))
+                    run(labels[tgt], i - 1)
+    run(0, len(lines))
+    return requests
+
+
+def _gfx950_kernels(src, pattern):
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-S", "--cuda-device-only", src, "-o", out], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    return re.findall(r"^(_ZN\S*" + pattern + r"[^\s:]*):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
+
+
+def test_hand_counted_gemm_loads_are_never_touched_before_their_wait():
+    """gemm_f32r.hip (row panel) and gemm_f32t.hip (A^T B) request operands with inline-asm global loads that hipcc does not
+    track -- its own s_waitcnt insertion drained the pipeline right after each request -- and count vmcnt by hand.  The
+    price: any compiler-made copy of a requested register between the request and the wait (a phi copy at a join or at a loop's
+    end, the set-up of a tied asm operand) reads a register the load has not written yet.  All three happened while the
+    kernels were written; one showed up as a test failing one run in four.  This compiles both files to gfx950 assembly and
+    checks every instantiation with the in-order vmcnt model."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "multimodal-isic_amd", "csrc")
+    rp = _gfx950_kernels(os.path.join(csrc, "gemm_f32r.hip"), "gemm_rowpanel_kernel")
+    assert len(rp) >= 16, "expected the KC = 1..8 x {plain, addend} instantiations"
+    tn = _gfx950_kernels(os.path.join(csrc, "gemm_f32t.hip"), "gemm_tn_skinny_kernel")
+    assert len(tn) == 1
+    for name, body in rp + tn:
+        assert _scan_requested_registers(name, body) > 0, name
+    # the checker itself: a copy in front of the wait, and a loop that carries a requested register over its back-edge
+    bad = ";;#ASMSTART\nglobal_load_dwordx4 v[10:13], v[2:3], off\n;;#ASMEND\nv_mov_b32_e32 v20, v11\ns_waitcnt vmcnt(0)\n"
+    with pytest.raises(AssertionError):
+        _scan_requested_registers("bad", bad)
+    loop = (".LBB0_1:\nv_mov_b64_e32 v[20:21], v[10:11]\n;;#ASMSTART\nglobal_load_dwordx4 v[10:13], v[2:3], off\n;;#ASMEND\n"
+            "s_cbranch_scc1 .LBB0_1\ns_waitcnt vmcnt(0)\n")
+    with pytest.raises(AssertionError):
+        _scan_requested_registers("loop", loop)
+    ok = (";;#ASMSTART\nglobal_load_dwordx4 v[10:13], v[2:3], off\n;;#ASMEND\nglobal_store_dwordx4 v[4:5], v[30:33], off\n"
+          ";;#ASMSTART\ns_waitcnt vmcnt(1)\n;;#ASMEND\nv_mov_b32_e32 v20, v11\n")
+    assert _scan_requested_registers("ok", ok) == 1
