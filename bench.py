@@ -236,7 +236,7 @@ def run_mil(args, world, rank, dev):
         with ops.fused_grad_accumulation():          # head gradients are added into the flat buffer by the kernels
             out = model(images[s], radiom[s])
             loss = model.loss(out, labels[s])
-            loss.backward()
+            ops.backward(loss)
         sync.finish()
         opt.step(grad_scale=1.0 / world)
         return loss
@@ -434,7 +434,7 @@ def run_gnn(args, world, rank, dev):
         with ops.fused_grad_accumulation():              # parameter gradients are added into the flat buffer by the kernels
             probs, _ = model(xb, offsets=ob, graph=gb)
             loss = ops.cross_entropy_from_probs(probs, store.y_dev[idx_static])
-            loss.backward()
+            ops.backward(loss)
         sync.finish()
         opt.step(grad_scale=1.0 / world)
         if clock is not None:

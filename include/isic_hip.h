@@ -90,6 +90,8 @@ int isic_tanh_bwd_f32(const float* dy, const float* t, float* dx, int64_t n, voi
 int isic_relu_dropout_fwd_f32(float* x, int64_t n, uint32_t drop_threshold, float drop_scale, uint64_t seed,
                               uint64_t stream_id, void* stream);
 int isic_relu_dropout_bwd_f32(const float* y, float* dy, int64_t n, float drop_scale, void* stream);
+/* ... out of place: dx = dy * mask (the upstream gradient is left intact: no copy in front of an in-place pass) */
+int isic_relu_dropout_bwd_out_f32(const float* y, const float* dy, float* dx, int64_t n, float drop_scale, void* stream);
 
 /* dst[i][0..count[i]) = (accumulate ? dst[i] : 0) + src[i][0..count[i])  for nseg <= 32 segments in ONE launch.  dst, src and
  * count are HOST arrays (read during the call; the pointers in them are device pointers).  The per-head attention

@@ -176,8 +176,9 @@ class LinearFn(torch.autograd.Function):
         x2, w, y = ctx.saved_tensors
         g = _f32c(dy.reshape(-1, w.shape[0]))
         if ctx.act == ACT_RELU:
-            g = g.clone() if g.data_ptr() == dy.data_ptr() else g
-            call("isic_relu_dropout_bwd_f32", y, g, g.numel(), ctx.drop_scale)
+            g2 = torch.empty_like(g)
+            call("isic_relu_dropout_bwd_out_f32", y, g, g2, g.numel(), ctx.drop_scale)
+            g = g2
         elif ctx.act == ACT_TANH:
             g2 = torch.empty_like(g)
             call("isic_tanh_bwd_f32", g, y, g2, g.numel())
@@ -468,12 +469,39 @@ class CrossEntropyFn(torch.autograd.Function):
         ctx.save_for_backward(d)
         ctx.xshape = inp.shape
         ctx.mark_non_differentiable(loss_ps)
+        ctx.set_materialize_grads(False)         # (no zero tensor -- a fill launch -- for the unused per-sample output)
         return loss.reshape(()), loss_ps
 
     @staticmethod
     def backward(ctx, dloss, _dps):
         (d,) = ctx.saved_tensors
+        if dloss is None:
+            return None, None, None
+        if _is_unit_grad(dloss):                 # ops.backward(loss): d loss / d loss = 1 by construction, no multiply launch
+            return d.reshape(ctx.xshape), None, None
         return (d * dloss).reshape(ctx.xshape), None, None
+
+
+_UNIT = {}
+
+
+def _unit_grad(device):
+    key = (device.type, device.index)
+    t = _UNIT.get(key)
+    if t is None:
+        t = _UNIT[key] = torch.ones((), device=device, dtype=torch.float32)
+    return t
+
+
+def _is_unit_grad(t):
+    u = _UNIT.get((t.device.type, t.device.index))
+    return u is not None and t.data_ptr() == u.data_ptr()
+
+
+def backward(loss):
+    """``loss.backward()`` for a scalar loss of this package without the two launches torch spends on d loss / d loss: the
+    seed gradient is a cached device scalar 1 (no fill), and the loss functions recognise it and skip their multiply."""
+    torch.autograd.backward(loss, grad_tensors=(_unit_grad(loss.device),))
 
 
 def cross_entropy(logits, labels):

@@ -139,7 +139,7 @@ def train_teacher_fold(model, train_bags, train_labels, val_bags, val_labels, *,
                 y = torch.as_tensor(np.asarray(train_labels)[mine], device=device)
                 # mean over the GLOBAL step: local mean * (local / global count), summed by the all-reduce
                 loss = ops.cross_entropy(out["bag_logits"], y) * (len(mine) * world / len(glob))
-                loss.backward()
+                ops.backward(loss)
             _sync_step(opt, sync, world)
         probs, val_loss = eval_teacher(model, va, val_labels)
         if len(val_labels) == 0:
@@ -462,7 +462,7 @@ def train_gnn_fold(model, train_records, val_records, test_records, *, lr=1e-4, 
                     probs, _ = model(x, offsets=offs, graph=g)
                     y = tr.y_dev[mine_dev]
                     loss = ops.cross_entropy_from_probs(probs, y) * (len(mine) * world / len(glob))
-                    loss.backward()
+                    ops.backward(loss)
             _sync_step(opt, sync, world)
         vm = evaluate_gnn(model, va, num_classes)
         if vm["bacc"] > best_bacc + min_delta:
