@@ -432,8 +432,7 @@ def run_gnn(args, world, rank, dev):
         opt.zero_grad()
         sync.reset()
         with ops.fused_grad_accumulation():              # parameter gradients are added into the flat buffer by the kernels
-            probs, _ = model(xb, offsets=ob, graph=gb)
-            loss = ops.cross_entropy_from_probs(probs, store.y_dev[idx_static])
+            probs, _, loss = model(xb, offsets=ob, graph=gb, labels=store.y_dev[idx_static])     # head + loss: one node
             ops.backward(loss)
         sync.finish()
         opt.step(grad_scale=1.0 / world)

@@ -101,6 +101,23 @@ int isic_relu_dropout_bwd_out_f32(const float* y, const float* dy, float* dx, in
 int isic_multi_copy_f32(int nseg, float* const* dst, const float* const* src, const int64_t* count, int accumulate,
                         void* stream);
 
+/* ------------------------------------------------------------------ GraphMIL classifier head + loss, forward and backward
+ * classifier_light of 05_train_gnns.py:136-139 (Linear(H, D) -> ReLU -> Dropout -> Linear(D, C)), softmax (:213-217) and
+ * F.cross_entropy(log(p + 1e-9), y) (:344) in two launches instead of sixteen dependent ones:
+ *   isic_graph_head_fwd_bwd  -> probs[B, C], loss_per_sample[B], loss_mean[1], dz[B, H] (for d loss = 1) and the blocks'
+ *                               contributions to the parameter gradients in `workspace` (isic_graph_head_workspace_bytes);
+ *                               `counter`: one zero uint32 (left zero); dropout as isic_relu_dropout_fwd_clk_f32 on [B, D];
+ *   isic_graph_head_param_grads: dW1[D, H], db1[D], dW2[C, D], db2[C] (+= when accumulate) = grad_scale[0] (device scalar,
+ *                               NULL = 1) * the contributions added in block order.  C <= 16. */
+size_t isic_graph_head_workspace_bytes(int B, int H, int D, int C);
+int isic_graph_head_fwd_bwd(const float* z, const float* W1, const float* b1, const float* W2, const float* b2,
+                            const int64_t* labels, int B, int H, int D, int C, uint32_t drop_threshold, float drop_scale,
+                            uint64_t seed, uint64_t stream_id, const uint64_t* clock, float* probs, float* loss_per_sample,
+                            float* loss_mean, float* dz, void* workspace, size_t workspace_bytes, uint32_t* counter,
+                            void* stream);
+int isic_graph_head_param_grads(const void* workspace, int B, int H, int D, int C, const float* grad_scale, float* dW1,
+                                float* db1, float* dW2, float* db2, int accumulate, void* stream);
+
 /* ------------------------------------------------------------------ device step clock (captured train steps)
  * A train step captured into a hipGraph replays the SAME kernel arguments, but two values must change from step to
  * step: the dropout stream id (step * 1024 + site, oracle/philox.py) and Adam's step count t.  The `_clk` forms of the

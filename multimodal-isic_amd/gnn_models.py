@@ -231,10 +231,12 @@ class GraphMIL(nn.Module):
         # 05:184-187 passes edge_weight to gcn / gcnii only
         return GraphBatch(edge_index, n_nodes, edge_weight if self.gnn_type in ("gcn", "gcnii") else None, mode=mode)
 
-    def forward(self, x, edge_index=None, edge_weight=None, offsets=None, graph=None):
+    def forward(self, x, edge_index=None, edge_weight=None, offsets=None, graph=None, labels=None):
         """x[N, D] (+ edge_index[2, E]) -> (probs[C], attention_weights[N, heads]) as the reference
         (`05_train_gnns.py:156-219`); with ``offsets`` (graph boundaries, global node ids) the batch
-        form returns probs[G, C]."""
+        form returns probs[G, C].  With ``labels`` [G] the loss of the train loop (`05:344`,
+        ``F.cross_entropy(log(probs + 1e-9), y)``) is the third return value -- and, for the classifier_light head in
+        training mode, head + loss are one autograd node (``ops.graph_head_loss``: two launches instead of sixteen)."""
         single = offsets is None
         offs = BagOffsets.single(x.shape[0], x.device) if single else as_offsets(offsets, x.device)
         clk, tr = self.dropout_clock, self.training
@@ -296,6 +298,11 @@ class GraphMIL(nn.Module):
         W2, b2, w3, b3 = ops.head_params(self.attention_layers)      # the heads' parameters as one [heads*A, H] operand
         z, att = ops.attn_pool(h, W2, b2, w3, b3, offs.device, offs.max_bag, heads=self.att_heads)
         c = self.classifier
+        if labels is not None and self.classifier_light and tr and not single:
+            probs, loss = ops.graph_head_loss(z, c[0].weight, c[0].bias, c[3].weight, c[3].bias, labels,
+                                              clk.spec(c[2].p, 64, tr))
+            clk.step += 1
+            return probs, att, loss
         if self.classifier_light:
             u = ops.linear(z, c[0].weight, c[0].bias, ops.ACT_RELU, clk.spec(c[2].p, 64, tr))
             logits = ops.linear(u, c[3].weight, c[3].bias)
@@ -308,4 +315,7 @@ class GraphMIL(nn.Module):
         probs = ops.softmax_rows(logits)
         if tr:
             clk.step += 1
+        if labels is not None:
+            y = labels.reshape(-1)
+            return (probs[0] if single else probs), att, ops.cross_entropy_from_probs(probs, y)
         return (probs[0], att) if single else (probs, att)

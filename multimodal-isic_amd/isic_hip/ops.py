@@ -482,6 +482,67 @@ class CrossEntropyFn(torch.autograd.Function):
         return (d * dloss).reshape(ctx.xshape), None, None
 
 
+# --------------------------------------------------------------------------- GraphMIL head + loss in two launches
+_HEAD_COUNTER = {}
+
+
+class GraphHeadLossFn(torch.autograd.Function):
+    """probs, loss = softmax(Linear(dropout(relu(Linear(z))))), mean CE(log(probs + 1e-9), labels): the classifier_light
+    head of GraphMIL and the loss of `05_train_gnns.py:344` as ONE autograd node.  The forward launch also computes every
+    gradient (for d loss = 1): dz and the blocks' contributions to the parameter gradients; the backward is one more launch
+    that adds the contributions into the parameters' gradients (times d loss).  ``probs`` is an output for the caller's
+    metrics: it takes no gradient."""
+
+    @staticmethod
+    def forward(ctx, z, W1, b1, W2, b2, labels, drop):
+        _chk(z, W1, b1, W2, b2, labels)
+        z2 = _f32c(z)
+        B, H = z2.shape
+        D, C = W1.shape[0], W2.shape[0]
+        drop = drop or NO_DROP
+        dev = z2.device
+        key = (dev.type, dev.index)
+        cnt = _HEAD_COUNTER.get(key)
+        if cnt is None:
+            cnt = _HEAD_COUNTER[key] = torch.zeros(64, device=dev, dtype=torch.int32)
+        probs = torch.empty((B, C), device=dev, dtype=torch.float32)
+        loss_ps = torch.empty((B,), device=dev, dtype=torch.float32)
+        loss = torch.empty((1,), device=dev, dtype=torch.float32)
+        dz = torch.empty_like(z2)
+        nbytes = int(call("isic_graph_head_workspace_bytes", B, H, D, C))
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)       # lives until the backward: not the shared workspace
+        call("isic_graph_head_fwd_bwd", z2, _f32c(W1), _f32c(b1), _f32c(W2), _f32c(b2),
+             labels.reshape(-1).to(torch.int64).contiguous(), B, H, D, C, drop.threshold, drop.scale, drop.seed, drop.stream,
+             drop.clock, probs, loss_ps, loss, dz, ws, nbytes, cnt)
+        ctx.params, ctx.dims, ctx.zshape = (W1, b1, W2, b2), (B, H, D, C), z.shape
+        ctx.save_for_backward(dz, ws)
+        ctx.mark_non_differentiable(probs, loss_ps)
+        ctx.set_materialize_grads(False)
+        return probs, loss.reshape(()), loss_ps
+
+    @staticmethod
+    def backward(ctx, _dprobs, dloss, _dps):
+        if dloss is None:
+            return (None,) * 7
+        dz, ws = ctx.saved_tensors
+        B, H, D, C = ctx.dims
+        W1, b1, W2, b2 = ctx.params
+        unit = _is_unit_grad(dloss)
+        gs = None if unit else _f32c(dloss).reshape(1)
+        tg = [_acc_target(p) for p in ctx.params]
+        fused = all(t is not None for t in tg)
+        outs = tg if fused else [torch.empty(p.shape, device=dz.device, dtype=torch.float32) for p in ctx.params]
+        call("isic_graph_head_param_grads", ws, B, H, D, C, gs, outs[0], outs[1], outs[2], outs[3], int(fused))
+        gz = (dz if unit else dz * dloss).reshape(ctx.zshape) if ctx.needs_input_grad[0] else None
+        return (gz,) + ((None,) * 4 if fused else tuple(outs)) + (None, None)
+
+
+def graph_head_loss(z, W1, b1, W2, b2, labels, drop=None):
+    """-> (probs[B, C], mean loss)."""
+    probs, loss, _ = GraphHeadLossFn.apply(z, W1, b1, W2, b2, labels, drop)
+    return probs, loss
+
+
 _UNIT = {}
 
 

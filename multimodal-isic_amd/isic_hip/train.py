@@ -459,10 +459,14 @@ def train_gnn_fold(model, train_records, val_records, test_records, *, lr=1e-4, 
                 mine_dev = order_dev[s + lo:s + hi]
                 x, offs, g = tr.batch(mine_dev if len(mine) > 1 else mine)
                 with ops.fused_grad_accumulation():          # zero_grad -> backward -> step: gradients go straight into the flat buffer
-                    probs, _ = model(x, offsets=offs, graph=g)
                     y = tr.y_dev[mine_dev]
-                    loss = ops.cross_entropy_from_probs(probs, y) * (len(mine) * world / len(glob))
-                    ops.backward(loss)
+                    w = len(mine) * world / len(glob)
+                    if hasattr(model, "classifier_light"):      # GraphMIL: head + loss as one autograd node (two launches)
+                        _probs, _att, loss = model(x, offsets=offs, graph=g, labels=y)
+                    else:
+                        probs, _ = model(x, offsets=offs, graph=g)
+                        loss = ops.cross_entropy_from_probs(probs, y)
+                    ops.backward(loss if w == 1.0 else loss * w)
             _sync_step(opt, sync, world)
         vm = evaluate_gnn(model, va, num_classes)
         if vm["bacc"] > best_bacc + min_delta:

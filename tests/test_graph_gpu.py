@@ -371,3 +371,38 @@ def test_heterophily_measures_vs_reference_golden_and_oracle():
         for k in ("H_kl", "H_dirichlet", "H_spatial", "H_compat_matrix", "lambda_2"):
             np.testing.assert_allclose(got[i][k], ref[k], rtol=2e-5, atol=2e-6, err_msg=f"image {i} {k}")
         assert abs(got[i]["H_adj"] - ref["H_adj"]) < 1e-9
+
+
+@pytest.mark.parametrize("p_drop,B", [(0.0, 37), (0.2, 256)])
+def test_graph_head_loss_fused_equals_the_operator_chain(p_drop, B):
+    """ops.graph_head_loss (classifier_light + softmax + the 05:344 loss, forward and backward in two launches) against the chain of
+    operators it replaces (linear / relu-dropout / linear / softmax_rows / cross_entropy_from_probs, each checked against the
+    oracle elsewhere): same dropout words, probabilities, loss and every gradient to fp32 summation-order tolerance; a ragged last
+    block (37 rows); a non-unit upstream gradient; bit-equal from run to run."""
+    from isic_hip import ops
+    gen = torch.Generator().manual_seed(23)
+    H, D, C = 128, 128, 7
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=gen) * sc).to(DEV).requires_grad_(True)
+    z, W1, b1, W2, b2 = mk(B, H), mk(D, H, sc=0.1), mk(D, sc=0.1), mk(C, D, sc=0.2), mk(C, sc=0.1)
+    y = torch.randint(0, C, (B,), generator=gen).to(DEV)
+    drop = ops.DropoutSpec(p_drop, seed=3, stream=64) if p_drop else None
+    params = (z, W1, b1, W2, b2)
+
+    def chain():
+        u = ops.linear(z, W1, b1, ops.ACT_RELU, drop)
+        probs = ops.softmax_rows(ops.linear(u, W2, b2))
+        return probs, ops.cross_entropy_from_probs(probs, y)
+    p0, l0 = chain()
+    g0 = torch.autograd.grad(l0 * 1.7, params)
+    runs = []
+    for _ in range(2):
+        p1, l1 = ops.graph_head_loss(z, W1, b1, W2, b2, y, drop)
+        runs.append((p1.clone(), l1.clone()) + tuple(g.clone() for g in torch.autograd.grad(l1 * 1.7, params)))
+    p1, l1, g1 = runs[0][0], runs[0][1], runs[0][2:]
+    assert_close(p1, p0, rtol=2e-5, atol=1e-6, what="probs")
+    assert_close(l1, l0, rtol=2e-6, atol=1e-6, what="loss")
+    for a, r, n in zip(g1, g0, ("z", "W1", "b1", "W2", "b2")):
+        assert_close(a, r, rtol=2e-4, atol=2e-7, what="d" + n)
+    for a, b in zip(runs[0], runs[1]):
+        assert torch.equal(a, b)
+    # through the model: GraphMIL(labels=...) in training mode == forward + cross_entropy_from_probs
