@@ -108,7 +108,7 @@ int isic_multi_copy_f32(int nseg, float* const* dst, const float* const* src, co
  *                               contributions to the parameter gradients in `workspace` (isic_graph_head_workspace_bytes);
  *                               `counter`: one zero uint32 (left zero); dropout as isic_relu_dropout_fwd_clk_f32 on [B, D];
  *   isic_graph_head_param_grads: dW1[D, H], db1[D], dW2[C, D], db2[C] (+= when accumulate) = grad_scale[0] (device scalar,
- *                               NULL = 1) * the contributions added in block order.  C <= 16. */
+ *                               NULL = 1) * the contributions added in block order.  C <= 15. */
 size_t isic_graph_head_workspace_bytes(int B, int H, int D, int C);
 int isic_graph_head_fwd_bwd(const float* z, const float* W1, const float* b1, const float* W2, const float* b2,
                             const int64_t* labels, int B, int H, int D, int C, uint32_t drop_threshold, float drop_scale,

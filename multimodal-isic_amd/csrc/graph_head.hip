@@ -44,16 +44,41 @@ __global__ __launch_bounds__(HT) void graph_head_kernel(HeadArgs a) {
   unsigned long long stream_id = a.stream_id;
   if (a.clock) stream_id += a.clock[0] * 1024ULL;          // device step clock (captured graphs)
 
-  for (int i = tid; i < D * H; i += HT) {
-    const float w = a.W1[i];
-    const int d = i / H, h = i - d * H;
-    W1s[i] = w;
-    W1t[h * (D + 1) + d] = w;
+  // (eight loads in flight per thread: a load -> LDS store loop waits a full L2 round trip per element -- 32 of them for W1)
+  for (int i0 = tid; i0 < D * H; i0 += 8 * HT) {
+    float w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = i0 + k * HT < D * H ? a.W1[i0 + k * HT] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k * HT;
+      if (i < D * H) {
+        const int d = i / H, h = i - d * H;
+        W1s[i] = w[k];
+        W1t[h * (D + 1) + d] = w[k];
+      }
+    }
   }
-  for (int i = tid; i < C * D; i += HT) W2s[i] = a.W2[i];
-  for (int i = tid; i < RH * H; i += HT) {
-    const int r = i / H;
-    zc[i] = r < nr ? a.z[(size_t)(r0 + r) * H + (i - r * H)] : 0.f;
+  {
+    float w[2], zv[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + k * HT;
+      w[k] = i < C * D ? a.W2[i] : 0.f;
+      const int r = i / H;
+      zv[k] = (i < RH * H && r < nr) ? a.z[(size_t)(r0 + r) * H + (i - r * H)] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + k * HT;
+      if (i < C * D) W2s[i] = w[k];
+      if (i < RH * H) zc[i] = zv[k];
+    }
+    for (int i = tid + 2 * HT; i < C * D; i += HT) W2s[i] = a.W2[i];
+    for (int i = tid + 2 * HT; i < RH * H; i += HT) {
+      const int r = i / H;
+      zc[i] = r < nr ? a.z[(size_t)(r0 + r) * H + (i - r * H)] : 0.f;
+    }
   }
   __syncthreads();
 
@@ -62,6 +87,7 @@ __global__ __launch_bounds__(HT) void graph_head_kernel(HeadArgs a) {
     const int r = o / D, d = o - r * D;
     float s = a.b1[d];
     const float* zr = zc + r * H;
+#pragma unroll 16
     for (int h = 0; h < H; ++h) s += zr[h] * W1t[h * (D + 1) + d];
     float v = fmaxf(s, 0.f);
     if (a.thr) v = philox_word((unsigned long long)(r0 + r) * D + d, a.seed, stream_id) >= a.thr ? v * a.scale : 0.f;
@@ -72,6 +98,7 @@ __global__ __launch_bounds__(HT) void graph_head_kernel(HeadArgs a) {
   for (int o = tid; o < RH * C; o += HT) {
     const int r = o / C, c = o - r * C;
     float s = a.b2[c];
+#pragma unroll 16
     for (int d = 0; d < D; ++d) s += h1[r * D + d] * W2s[c * D + d];
     lg[r * MAXC + c] = s;
   }
@@ -91,7 +118,9 @@ __global__ __launch_bounds__(HT) void graph_head_kernel(HeadArgs a) {
     float qs = 0.f;
     for (int c = 0; c < C; ++c) qs += expf(logf(p[c] + 1e-9f) - qm);
     const float lse = qm + logf(qs);
-    a.loss_ps[r0 + r] = lse - logf(p[y] + 1e-9f);
+    const float lossr = lse - logf(p[y] + 1e-9f);
+    a.loss_ps[r0 + r] = lossr;
+    lg[r * MAXC + MAXC - 1] = lossr;                       // (C < MAXC: the slot is free) for the block's loss sum
     const float gs = 1.f / (float)a.B;
     float dot = 0.f;
     for (int c = 0; c < C; ++c) {
@@ -115,6 +144,7 @@ __global__ __launch_bounds__(HT) void graph_head_kernel(HeadArgs a) {
   for (int o = tid; o < RH * H; o += HT) {
     const int r = o / H, h = o - r * H;
     float s = 0.f;
+#pragma unroll 16
     for (int d = 0; d < D; ++d) s += g1[r * D + d] * W1s[d * H + h];
     if (r < nr) a.dz[(size_t)(r0 + r) * H + h] = s;
   }
@@ -146,23 +176,24 @@ __global__ __launch_bounds__(HT) void graph_head_kernel(HeadArgs a) {
     for (int r = 0; r < RH; ++r) s += dl[r * MAXC + c];
     part[D * H + D + C * D + c] = s;
   }
-  // ---- the mean loss: by the block that finishes last, over all rows in row order
-  __shared__ unsigned int ticket;
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) ticket = atomicAdd(a.counter, 1u);
-  __syncthreads();
-  if (ticket == gridDim.x - 1) {
-    __threadfence();
-    float acc = 0.f;
-    for (int b = tid; b < a.B; b += HT) acc += __builtin_nontemporal_load(a.loss_ps + b);
-    red[tid] = acc;
-    __syncthreads();
-    for (int s = HT / 2; s > 0; s >>= 1) {
-      if (tid < s) red[tid] += red[tid + s];
-      __syncthreads();
+  // ---- the mean loss: every block parks the sum of its rows' losses (row order), the block that finishes last adds the
+  //      blocks' sums in block order.  Device-scope ATOMICS only (performed at the coherent level): a __threadfence() pair
+  //      per block writes back / invalidates the XCD's whole L2 -- 30 us of this kernel when it was written that way.
+  if (tid == 0) {
+    float bs = 0.f;
+    for (int r = 0; r < nr; ++r) bs += lg[r * MAXC + MAXC - 1];                       // (the row's loss, parked next to its logits)
+    float* slot = a.partial + (size_t)gridDim.x * (D * H + D + C * D + C) + blockIdx.x;
+    (void)__hip_atomic_exchange(slot, bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the exchange has returned = it is performed, before the ticket
+    unsigned int t = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) {
+      float acc = 0.f;
+      const float* base = a.partial + (size_t)gridDim.x * (D * H + D + C * D + C);
+      for (unsigned int b = 0; b < gridDim.x; ++b)
+        acc += __hip_atomic_load(base + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a.loss_mean[0] = acc / (float)a.B;
+      __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (tid == 0) { a.loss_mean[0] = red[0] / (float)a.B; *a.counter = 0u; }
   }
 }
 
@@ -191,7 +222,7 @@ extern "C" {
 
 size_t isic_graph_head_workspace_bytes(int B, int H, int D, int C) {
   if (B <= 0 || H <= 0 || D <= 0 || C <= 0) return 0;
-  return (size_t)ceil_div(B, RH) * ((size_t)D * H + D + (size_t)C * D + C) * sizeof(float);
+  return (size_t)ceil_div(B, RH) * ((size_t)D * H + D + (size_t)C * D + C + 1) * sizeof(float);   // + the block's loss sum
 }
 
 int isic_graph_head_fwd_bwd(const float* z, const float* W1, const float* b1, const float* W2, const float* b2,
@@ -201,7 +232,7 @@ int isic_graph_head_fwd_bwd(const float* z, const float* W1, const float* b1, co
                             void* stream) {
   ISIC_CHECK_ARG(B > 0 && H > 0 && D > 0 && C > 0);
   ISIC_CHECK_ARG(z && W1 && b1 && W2 && b2 && labels && probs && loss_per_sample && loss_mean && dz && workspace && counter);
-  if (C > MAXC) return ISIC_ERR_UNSUPPORTED;
+  if (C >= MAXC) return ISIC_ERR_UNSUPPORTED;
   const size_t lds = head_lds_bytes(H, D, C);
   if (lds > 160 * 1024 - 256) return ISIC_ERR_UNSUPPORTED;   // (the kernel has a few static bytes of its own)
   if (workspace_bytes < isic_graph_head_workspace_bytes(B, H, D, C) || (reinterpret_cast<uintptr_t>(workspace) & 15))
