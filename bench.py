@@ -428,11 +428,12 @@ def run_gnn(args, world, rank, dev):
     idx_static = torch.zeros(Gs, device=dev, dtype=torch.int64)
 
     def body():
-        xb, ob, gb = store.batch(idx_static)
+        xb, rows, n_rows, ob, gb = store.batch_rows(idx_static)      # no gather: the input projection reads through `rows`
         opt.zero_grad()
         sync.reset()
         with ops.fused_grad_accumulation():              # parameter gradients are added into the flat buffer by the kernels
-            probs, _, loss = model(xb, offsets=ob, graph=gb, labels=store.y_dev[idx_static])     # head + loss: one node
+            probs, _, loss = model(xb, offsets=ob, graph=gb, labels=store.y_dev[idx_static],      # head + loss: one node
+                                   x_rows=(rows, n_rows))
             ops.backward(loss)
         sync.finish()
         opt.step(grad_scale=1.0 / world)

@@ -66,6 +66,15 @@ size_t isic_gemm_f32_workspace_bytes(int transA, int transB, int M, int N, int K
 int isic_gemm_f32_ws(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                      float* C, int ldc, const float* bias, int act, float beta, void* workspace, size_t workspace_bytes,
                      void* stream);
+/* ... with a row index on an operand: stored row r of A (of B) is read from A[a_rows[r]] (B[b_rows[r]]).  A step's batch of
+ * graphs is multiplied straight out of the resident record store -- x[sel] W^T and dY^T x[sel] -- without materialising the
+ * gathered node features (05_train_gnns.py:340-343 re-uploads them every step).  The index arrays are read in groups of 8
+ * (allocate a multiple of 8 entries).  Supported for the operand that forms the row tiles of the persistent kernel
+ * (A of a large product with > 128 output rows; B of a transA product with <= 128 output rows); ISIC_ERR_UNSUPPORTED
+ * otherwise -- gather, then isic_gemm_f32_ws.  Both NULL: isic_gemm_f32_ws. */
+int isic_gemm_f32_rows_ws(int transA, int transB, int M, int N, int K, const float* A, int lda, const int32_t* a_rows,
+                          const float* B, int ldb, const int32_t* b_rows, float* C, int ldc, const float* bias, int act,
+                          float beta, void* workspace, size_t workspace_bytes, void* stream);
 /* ... + addend[M, N] (leading dimension ldadd; NULL: isic_gemm_f32_ws) added to the result: the second gradient path of a
  * residual connection joins in the GEMM's epilogue instead of in an elementwise pass over both
  * (05_train_gnns.py:187-199: h = h_prev + dropout(relu(LN(conv(h_prev)))) -> dh_prev = dY + dConv W). */
@@ -330,7 +339,8 @@ int isic_gcn_csr_build(const int64_t* src, const int64_t* dst, const float* edge
 int isic_csr_batch_assemble(const int64_t* sel, int B, int n, int nnz, const int32_t* rowptr, const int32_t* rowptr_t,
                             const int32_t* col, const int32_t* col_t, const float* val, const float* val_t,
                             const int32_t* perm_t, int32_t* rowptr_out, int32_t* rowptr_t_out, int32_t* col_out,
-                            int32_t* col_t_out, float* val_out, float* val_t_out, int32_t* perm_t_out, void* stream);
+                            int32_t* col_t_out, float* val_out, float* val_t_out, int32_t* perm_t_out, int32_t* row_index_out,
+                            void* stream);
 /* out[i,:] = alpha * sum_{e in row i} val[e] * x[col[e],:] (+ bias) (+ addend_scale*addend[i,:])
  * -- the neighbour gather / segmented sum of GCNConv.propagate
  * (05_train_gnns.py:184-185); GCN2Conv's (1-alpha) A^ x + alpha x_0 with addend.

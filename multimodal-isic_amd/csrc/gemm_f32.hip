@@ -19,6 +19,9 @@ int isic_gemm_f32p_launch(int transA, int transB, int M, int N, int K, const flo
                           float* C, int ldc, const float* bias, int act, float beta, void* workspace,
                           size_t workspace_bytes, hipStream_t stream);
 
+int isic_gemm_f32p_rows_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const int* a_rows,
+                               const float* B, int ldb, const int* b_rows, float* C, int ldc, const float* bias, int act,
+                               float beta, void* workspace, size_t workspace_bytes, hipStream_t stream);
 // register-fed split-K kernel for A^T B with a small output and a long reduction (gemm_f32t.hip)
 size_t isic_gemm_f32t_workspace_bytes(int transA, int transB, int M, int N, int K);
 int isic_gemm_f32t_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
@@ -437,6 +440,18 @@ int isic_gemm_f32_ws(int transA, int transB, int M, int N, int K, const float* A
                      void* stream) {
   return isic_test_gemm_f32_variant(0, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, beta, workspace,
                                     workspace_bytes, stream);
+}
+
+int isic_gemm_f32_rows_ws(int transA, int transB, int M, int N, int K, const float* A, int lda, const int32_t* a_rows,
+                          const float* B, int ldb, const int32_t* b_rows, float* C, int ldc, const float* bias, int act,
+                          float beta, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!a_rows && !b_rows)
+    return isic_gemm_f32_ws(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, beta, workspace, workspace_bytes, stream);
+  ISIC_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C);
+  ISIC_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N);
+  ISIC_CHECK_ARG(act >= ISIC_ACT_NONE && act <= ISIC_ACT_TANH);
+  return isic_gemm_f32p_rows_launch(transA, transB, M, N, K, A, lda, a_rows, B, ldb, b_rows, C, ldc, bias, act, beta, workspace,
+                                    workspace_bytes, as_stream(stream));      // ISIC_ERR_UNSUPPORTED: gather first, then isic_gemm_f32_ws
 }
 
 int isic_gemm_f32_add_ws(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,

@@ -41,6 +41,7 @@ struct G32Args {
   float* C;                // [M][ldc], or [N][ldc] when transC
   float* partial;          // split-K: [splits][M][N] raw sums (N % 4 == 0), else null
   const float* bias;       // [N] or null
+  const int* arow;         // or null: row r of the kernel's A operand (m for AK, k otherwise) is stored row arow[r] of A
   int M, N, K, lda, ldb, ldc;
   int act, transC, vecC;   // vecC: 16-byte stores into C are legal (ldc % 4 == 0, aligned, N % 4 == 0)
   float beta;
@@ -54,6 +55,25 @@ __device__ __forceinline__ void g32_glds16(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// Row indices of a gathered operand are read with SCALAR loads (lgkmcnt): the staging waves count vmcnt by hand, a vector
+// load among their LDS-DMAs would break the count.  The address is wave-uniform by construction.
+typedef int g32_i8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ g32_i8 g32_sload8(const int* base_uniform) {
+  const unsigned long long q = (unsigned long long)base_uniform;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)q), hi = __builtin_amdgcn_readfirstlane((unsigned)(q >> 32));
+  const unsigned long long qs = ((unsigned long long)hi << 32) | lo;
+  g32_i8 v;
+  asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(qs) : "memory");
+  return v;
+}
+__device__ __forceinline__ int g32_sload1(const int* p_uniform) {
+  const unsigned long long q = (unsigned long long)p_uniform;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)q), hi = __builtin_amdgcn_readfirstlane((unsigned)(q >> 32));
+  const unsigned long long qs = ((unsigned long long)hi << 32) | lo;
+  int v;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(qs) : "memory");
+  return v;
 }
 
 __device__ __forceinline__ float g32_act(float v, int act) {
@@ -91,9 +111,18 @@ __global__ __launch_bounds__(1024) void gemm_f32p_kernel(G32Args a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (AK) {
-          const int m = m0 + 8 * (sw + 8 * i) + r8;
+          const int mb = m0 + 8 * (sw + 8 * i);            // wave-uniform; rows mb .. mb + 7, one per r8
+          const int m = mb + r8;
           a_ok[i] = m < a.M;
-          a_ptr[i] = a.A + (size_t)(a_ok[i] ? m : 0) * a.lda + gch * 4;
+          int src = a_ok[i] ? m : 0;
+          if (a.arow && mb < a.M) {                        // gathered rows (the index array is padded to a multiple of 8)
+            const g32_i8 v = g32_sload8(a.arow + mb);
+            int pick = v[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) pick = r8 == q ? v[q] : pick;
+            src = a_ok[i] ? pick : 0;
+          }
+          a_ptr[i] = a.A + (size_t)src * a.lda + gch * 4;
         } else {
           const int k = sw + 8 * i;                        // k row inside the K-tile
           const int m = m0 + 4 * (lane ^ (((k >> 2) & 3) << 2));
@@ -128,7 +157,11 @@ __global__ __launch_bounds__(1024) void gemm_f32p_kernel(G32Args a) {
           // a 16-byte chunk holds k0 + 4 gch .. + 3: K % 4 == 0 (host), so it is inside or outside as a whole
           src = (live && a_ok[i] && k0 + gch * 4 < a.K) ? (const void*)(a_ptr[i] + k0) : (const void*)zp;
         } else {
-          src = (live && a_ok[i] && k0 + sw + 8 * i < a.K) ? (const void*)(a_ptr[i] + (size_t)k0 * a.lda) : (const void*)zp;
+          const bool in = live && k0 + sw + 8 * i < a.K;   // wave-uniform
+          size_t roff = (size_t)k0 * a.lda;                // a_ptr[i] already holds row sw + 8 i
+          if (a.arow && in)                                // gathered k rows: stored row arow[k] instead of row k
+            roff = (size_t)g32_sload1(a.arow + k0 + sw + 8 * i) * a.lda - (size_t)(sw + 8 * i) * a.lda;
+          src = (in && a_ok[i]) ? (const void*)(a_ptr[i] + roff) : (const void*)zp;
         }
         g32_glds16(src, live ? sbase + (unsigned)((sw + 8 * i) * 1024) : scr);
       }
@@ -359,9 +392,23 @@ size_t isic_gemm_f32p_workspace_bytes(int transA, int transB, int M, int N, int 
 
 // Returns ISIC_ERR_UNSUPPORTED when the shape / alignment is not for this kernel (the caller falls back to the 64 x 64
 // kernel), ISIC_OK after launching.
+int isic_gemm_f32p_rows_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const int* a_rows,
+                               const float* B, int ldb, const int* b_rows, float* C, int ldc, const float* bias, int act,
+                               float beta, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 int isic_gemm_f32p_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                           float* C, int ldc, const float* bias, int act, float beta, void* workspace,
                           size_t workspace_bytes, hipStream_t stream) {
+  return isic_gemm_f32p_rows_launch(transA, transB, M, N, K, A, lda, nullptr, B, ldb, nullptr, C, ldc, bias, act, beta, workspace,
+                                    workspace_bytes, stream);
+}
+
+// ... with a row index on an operand: stored row r of A (of B) is taken from A[a_rows[r]] (B[b_rows[r]]): a batch of graphs is
+// multiplied straight out of the resident record store, without materialising the gathered rows.  Only for the operand that
+// ends up as the kernel's row-tile operand (x in x W^T; X in dY^T X with <= 128 output rows); ISIC_ERR_UNSUPPORTED otherwise.
+int isic_gemm_f32p_rows_launch(int transA, int transB, int M, int N, int K, const float* A, int lda, const int* a_rows,
+                               const float* B, int ldb, const int* b_rows, float* C, int ldc, const float* bias, int act,
+                               float beta, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   G32Plan p = g32_plan(transA, transB, M, N, K);
   if (!p.ok || lda % 4 != 0 || ldb % 4 != 0 || !aligned16(A) || !aligned16(B)) return ISIC_ERR_UNSUPPORTED;
   if ((int64_t)(M > N ? M : N) * ldc >= (1LL << 31)) return ISIC_ERR_UNSUPPORTED;      // 32-bit element offsets into C
@@ -373,7 +420,9 @@ int isic_gemm_f32p_launch(int transA, int transB, int M, int N, int K, const flo
     p.tiles_per_block = ceil_div(p.mtiles, groups);
     p.gx = ceil_div(p.mtiles, p.tiles_per_block);
   }
+  if ((!p.swap && b_rows) || (p.swap && a_rows)) return ISIC_ERR_UNSUPPORTED;       // only the row-tile operand gathers
   G32Args a;
+  a.arow = p.swap ? b_rows : a_rows;
   a.bias = bias; a.act = act; a.beta = beta; a.C = C; a.ldc = ldc;
   a.K = K; a.Ktiles = ceil_div(K, PK); a.kt_per_split = p.kt_per_split; a.splits = p.splits;
   a.mtiles = p.mtiles; a.tiles_per_block = p.tiles_per_block;

@@ -444,7 +444,8 @@ __global__ __launch_bounds__(256) void csr_batch_assemble_kernel(
     const int64_t* __restrict__ sel, int B, int n, int nnz, const int* __restrict__ rowptr, const int* __restrict__ rowptr_t,
     const int* __restrict__ col, const int* __restrict__ col_t, const float* __restrict__ val, const float* __restrict__ val_t,
     const int* __restrict__ perm_t, int* __restrict__ rowptr_o, int* __restrict__ rowptr_t_o, int* __restrict__ col_o,
-    int* __restrict__ col_t_o, float* __restrict__ val_o, float* __restrict__ val_t_o, int* __restrict__ perm_t_o) {
+    int* __restrict__ col_t_o, float* __restrict__ val_o, float* __restrict__ val_t_o, int* __restrict__ perm_t_o,
+    int* __restrict__ rowidx_o) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t ne = (int64_t)B * nnz, nr = (int64_t)B * n;
   if (i < ne) {
@@ -461,6 +462,7 @@ __global__ __launch_bounds__(256) void csr_batch_assemble_kernel(
     const int64_t src = sel[b] * n + r;
     rowptr_o[i] = rowptr[src] + b * nnz;
     rowptr_t_o[i] = rowptr_t[src] + b * nnz;
+    if (rowidx_o) rowidx_o[i] = (int)src;                  // node row b*n + r of the batch = row sel[b]*n + r of the record store
   } else if (i == nr) {
     rowptr_o[i] = (int)ne;
     rowptr_t_o[i] = (int)ne;
@@ -565,7 +567,8 @@ int isic_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* va
 int isic_csr_batch_assemble(const int64_t* sel, int B, int n, int nnz, const int32_t* rowptr, const int32_t* rowptr_t,
                             const int32_t* col, const int32_t* col_t, const float* val, const float* val_t,
                             const int32_t* perm_t, int32_t* rowptr_out, int32_t* rowptr_t_out, int32_t* col_out,
-                            int32_t* col_t_out, float* val_out, float* val_t_out, int32_t* perm_t_out, void* stream) {
+                            int32_t* col_t_out, float* val_out, float* val_t_out, int32_t* perm_t_out, int32_t* row_index_out,
+                            void* stream) {
   ISIC_CHECK_ARG(B >= 0 && n > 0 && nnz >= 0);
   if (B == 0) return ISIC_OK;
   ISIC_CHECK_ARG(sel && rowptr && rowptr_t && col && col_t && val && val_t && perm_t && rowptr_out && rowptr_t_out && col_out &&
@@ -575,7 +578,7 @@ int isic_csr_batch_assemble(const int64_t* sel, int B, int n, int nnz, const int
   const int64_t work = ne > nr ? ne : nr;
   hipLaunchKernelGGL(csr_batch_assemble_kernel, dim3((unsigned)ceil_div64(work, 256)), dim3(256), 0, as_stream(stream), sel, B, n,
                      nnz, rowptr, rowptr_t, col, col_t, val, val_t, perm_t, rowptr_out, rowptr_t_out, col_out, col_t_out,
-                     val_out, val_t_out, perm_t_out);
+                     val_out, val_t_out, perm_t_out, row_index_out);
   return isic_launch_status();
 }
 

@@ -231,17 +231,26 @@ class GraphMIL(nn.Module):
         # 05:184-187 passes edge_weight to gcn / gcnii only
         return GraphBatch(edge_index, n_nodes, edge_weight if self.gnn_type in ("gcn", "gcnii") else None, mode=mode)
 
-    def forward(self, x, edge_index=None, edge_weight=None, offsets=None, graph=None, labels=None):
+    def forward(self, x, edge_index=None, edge_weight=None, offsets=None, graph=None, labels=None, x_rows=None):
         """x[N, D] (+ edge_index[2, E]) -> (probs[C], attention_weights[N, heads]) as the reference
         (`05_train_gnns.py:156-219`); with ``offsets`` (graph boundaries, global node ids) the batch
         form returns probs[G, C].  With ``labels`` [G] the loss of the train loop (`05:344`,
         ``F.cross_entropy(log(probs + 1e-9), y)``) is the third return value -- and, for the classifier_light head in
-        training mode, head + loss are one autograd node (``ops.graph_head_loss``: two launches instead of sixteen)."""
+        training mode, head + loss are one autograd node (``ops.graph_head_loss``: two launches instead of sixteen).
+        ``x_rows = (rows, n_rows)``: ``x`` is a record store [R, D] and the batch's node row i is ``x[rows[i]]``
+        (``train.GraphStore.batch_rows``): the input projection reads through the index, the gather never happens."""
         single = offsets is None
-        offs = BagOffsets.single(x.shape[0], x.device) if single else as_offsets(offsets, x.device)
+        if x_rows is not None and (offsets is None or self.input_proj is None):
+            x = x[x_rows[0][:x_rows[1]].long()]            # no projection to read through the index: gather after all
+            x_rows = None
+        n_nodes = x_rows[1] if x_rows is not None else x.shape[0]
+        offs = BagOffsets.single(n_nodes, x.device) if single else as_offsets(offsets, x.device)
         clk, tr = self.dropout_clock, self.training
-        g = self._graph(edge_index, edge_weight, x.shape[0], graph)
-        x_in = ops.linear(x, self.input_proj.weight, self.input_proj.bias) if self.input_proj is not None else x
+        g = self._graph(edge_index, edge_weight, n_nodes, graph)
+        if x_rows is not None:
+            x_in = ops.linear_rows(x, x_rows[0], n_nodes, self.input_proj.weight, self.input_proj.bias)
+        else:
+            x_in = ops.linear(x, self.input_proj.weight, self.input_proj.bias) if self.input_proj is not None else x
         h, x0 = x_in, x_in
         p_drop = self.gnn_dropout.p
         for i, layer in enumerate(self.gnn_layers):

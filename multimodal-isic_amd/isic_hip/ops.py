@@ -202,6 +202,72 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+class LinearRowsFn(torch.autograd.Function):
+    """y = x_store[rows] W^T + b without materialising x_store[rows]: the GEMM reads its row operand through the index (forward:
+    A rows; weight gradient dW = dY^T x_store[rows]: the k rows of B) -- `isic_gemm_f32_rows_ws`.  The input projection of a
+    batch of graphs straight out of the resident record store (`05_train_gnns.py:340-343` re-uploads the node features of
+    every graph at every step; round 2 gathered them with an index_select: 154 MB read + written per step).  ``x_store`` takes
+    no gradient.  Shapes the gathering kernel does not take fall back to gather + ``linear``."""
+
+    @staticmethod
+    def forward(ctx, x_store, rows, n_rows, weight, bias):
+        _chk(x_store, weight, bias)
+        xs, w = _f32c(x_store), _f32c(weight)
+        b = _f32c(bias) if bias is not None else None
+        M, K, N = int(n_rows), xs.shape[1], w.shape[0]
+        if rows.dtype != torch.int32 or not rows.is_cuda or rows.numel() < (M + 7) // 8 * 8:
+            raise IsicHipError("linear_rows: rows must be a device int32 tensor padded to a multiple of 8 entries")
+        y = torch.empty((M, N), device=xs.device, dtype=torch.float32)
+        ws = _workspace(call("isic_gemm_f32_workspace_bytes", 0, 1, M, N, K), xs.device)
+        try:
+            call("isic_gemm_f32_rows_ws", 0, 1, M, N, K, xs, K, rows, w, K, None, y, N, b, ACT_NONE, 0.0, ws,
+                 ws.numel() if ws is not None else 0)
+            ctx.gathered = None
+        except IsicHipError as e:
+            if "UNSUPPORTED" not in str(e):
+                raise
+            ctx.gathered = xs[rows[:M].long()]
+            gemm(ctx.gathered, w, trans_b=True, bias=b, out=y)
+        ctx.params, ctx.M = (weight, bias), M
+        ctx.save_for_backward(xs, rows)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, rows = ctx.saved_tensors
+        weight, bias = ctx.params
+        g = _f32c(dy)
+        M, N, K = ctx.M, g.shape[1], xs.shape[1]
+        dw = db = None
+        if ctx.needs_input_grad[3]:
+            tgt = _acc_target(weight)
+            out = tgt if tgt is not None else torch.empty((N, K), device=g.device, dtype=torch.float32)
+            beta = 1.0 if tgt is not None else 0.0
+            if ctx.gathered is not None:
+                gemm(g, ctx.gathered, trans_a=True, out=out, beta=beta)
+            else:
+                ws = _workspace(call("isic_gemm_f32_workspace_bytes", 1, 0, N, K, M), g.device)
+                try:
+                    call("isic_gemm_f32_rows_ws", 1, 0, N, K, M, g, N, None, xs, K, rows, out, K, None, ACT_NONE, beta, ws,
+                         ws.numel() if ws is not None else 0)
+                except IsicHipError as e:
+                    if "UNSUPPORTED" not in str(e):
+                        raise
+                    gemm(g, xs[rows[:M].long()], trans_a=True, out=out, beta=beta)
+            dw = None if tgt is not None else out
+        if bias is not None and ctx.needs_input_grad[4]:
+            tgt = _acc_target(bias)
+            if tgt is not None:
+                colsum(g, out=tgt, beta=1.0)
+            else:
+                db = colsum(g)
+        return None, None, None, dw, db
+
+
+def linear_rows(x_store, rows, n_rows, weight, bias=None):
+    return LinearRowsFn.apply(x_store, rows, n_rows, weight, bias)
+
+
 def linear(x, weight, bias=None, act=ACT_NONE, drop=None):
     return LinearFn.apply(x, weight, bias, act, drop)
 

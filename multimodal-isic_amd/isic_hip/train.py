@@ -346,8 +346,9 @@ class GraphStore:
             "perm_t": (full.perm_t[:used].view(G, nnz).to(torch.int64) - eoff).to(i32),
         }
 
-    def _stacked_graph(self, sel):
-        """``sel``: device int64 tensor of graph indices."""
+    def _stacked_graph(self, sel, rows_out=None):
+        """``sel``: device int64 tensor of graph indices.  ``rows_out``: int32 [>= B*n] that receives, for every node row of the
+        batch, its row in the stacked record store (``batch_rows``)."""
         st = self._stack
         n, nnz, B = st["n"], st["nnz"], int(sel.numel())
         i32, dev = torch.int32, self.device
@@ -359,8 +360,21 @@ class GraphStore:
         # ONE launch (graph.hip: csr_batch_assemble_kernel) instead of seven index_selects + offset adds + concatenations
         call("isic_csr_batch_assemble", sel, B, n, nnz, st["rowptr"], st["rowptr_t"], st["col"], st["col_t"], st["val"],
              st["val_t"], st["perm_t"], parts["rowptr"], parts["rowptr_t"], parts["col"], parts["col_t"], parts["val"],
-             parts["val_t"], parts["perm_t"])
+             parts["val_t"], parts["perm_t"], rows_out)
         return GraphBatch.from_parts(B * n, B * (nnz - (n if self.mode == "gcn" else 0)), self.mode, parts)
+
+    def batch_rows(self, idx):
+        """The batch WITHOUT gathering its node features: (x_store[G*n, D], rows int32, n_rows, offsets, GraphBatch) with
+        batch node row i = x_store[rows[i]] -- for ``GraphMIL(x_store, x_rows=(rows, n_rows), ...)``, whose input projection
+        reads through the index (``ops.linear_rows``).  Equal-sized graphs with a stacked CSR and a device index only;
+        ``None`` otherwise (use ``batch``)."""
+        if not (isinstance(idx, torch.Tensor) and idx.is_cuda) or self._xstack is None or self._stack is None or not self.needs_graph:
+            return None
+        sel = idx.to(torch.int64)
+        B, n, D = int(sel.numel()), int(self._xstack.shape[1]), int(self._xstack.shape[2])
+        rows = torch.empty((B * n + 7) // 8 * 8 + 8, device=self.device, dtype=torch.int32)
+        graph = self._stacked_graph(sel, rows_out=rows)
+        return self._xstack.view(-1, D), rows, B * n, BagOffsets.uniform(B, n, self.device), graph
 
     def batch(self, idx, cache=False):
         """(x[sum n, D], offsets, GraphBatch) of the graphs ``idx`` (a list, or an int64 tensor already on the device:
@@ -457,12 +471,18 @@ def train_gnn_fold(model, train_records, val_records, test_records, *, lr=1e-4, 
             sync.reset()
             if mine:
                 mine_dev = order_dev[s + lo:s + hi]
-                x, offs, g = tr.batch(mine_dev if len(mine) > 1 else mine)
+                br = tr.batch_rows(mine_dev) if len(mine) > 1 and hasattr(model, "classifier_light") else None
+                if br is not None:                           # equal-sized graphs: no gather, the projection reads through the index
+                    x, rows, n_rows, offs, g = br
+                    xr = (rows, n_rows)
+                else:
+                    x, offs, g = tr.batch(mine_dev if len(mine) > 1 else mine)
+                    xr = None
                 with ops.fused_grad_accumulation():          # zero_grad -> backward -> step: gradients go straight into the flat buffer
                     y = tr.y_dev[mine_dev]
                     w = len(mine) * world / len(glob)
                     if hasattr(model, "classifier_light"):      # GraphMIL: head + loss as one autograd node (two launches)
-                        _probs, _att, loss = model(x, offsets=offs, graph=g, labels=y)
+                        _probs, _att, loss = model(x, offsets=offs, graph=g, labels=y, x_rows=xr)
                     else:
                         probs, _ = model(x, offsets=offs, graph=g)
                         loss = ops.cross_entropy_from_probs(probs, y)

@@ -406,3 +406,30 @@ def test_graph_head_loss_fused_equals_the_operator_chain(p_drop, B):
     for a, b in zip(runs[0], runs[1]):
         assert torch.equal(a, b)
     # through the model: GraphMIL(labels=...) in training mode == forward + cross_entropy_from_probs
+
+
+def test_linear_rows_reads_through_the_index_like_gather_then_linear():
+    """ops.linear_rows (isic_gemm_f32_rows_ws: the persistent GEMM reads its row operand through an int32 index, forward as A rows,
+    weight gradient as the k rows of B) == gather + ops.linear bit for bit (same kernel, same summation order), on a batch of
+    256 x 196 rows drawn with repeats from a 300-graph store; and GraphStore.batch_rows + GraphMIL(x_rows=...) == batch + GraphMIL."""
+    from isic_hip import ops
+    gen = torch.Generator().manual_seed(31)
+    G, n, D, F = 300, 196, 768, 128
+    store = torch.randn(G * n, D, generator=gen).to(DEV)
+    sel = torch.randint(0, G, (256,), generator=gen)
+    rows = (sel.view(-1, 1) * n + torch.arange(n).view(1, -1)).reshape(-1).to(torch.int32)
+    M = rows.numel()
+    rows_pad = torch.cat([rows, torch.zeros(8, dtype=torch.int32)]).to(DEV)
+    W = (torch.randn(F, D, generator=gen) * 0.05).to(DEV).requires_grad_(True)
+    b = torch.randn(F, generator=gen).to(DEV).requires_grad_(True)
+    dy = torch.randn(M, F, generator=gen).to(DEV)
+    y0 = ops.linear(store[rows.to(DEV).long()], W, b)
+    g0 = torch.autograd.grad(y0, (W, b), dy)
+    y1 = ops.linear_rows(store, rows_pad, M, W, b)
+    g1 = torch.autograd.grad(y1, (W, b), dy)
+    assert torch.equal(y1, y0), (y1 - y0).abs().max().item()
+    assert torch.equal(g1[0], g0[0]), (g1[0] - g0[0]).abs().max().item()
+    assert torch.equal(g1[1], g0[1])
+    # a shape the gathering kernel does not take (small M) falls back to gather + linear
+    y2 = ops.linear_rows(store, rows_pad, 64, W, b)
+    assert_close(y2, y0[:64], rtol=2e-5, atol=2e-5, what="fallback")
