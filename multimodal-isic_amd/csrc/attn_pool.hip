@@ -77,15 +77,23 @@ __global__ __launch_bounds__(NTHR) void attn_pool_fwd_kernel(PoolArgs a) {
   for (int c = 0; c < MAX_C; ++c) accP[c] = 0.f;
 
   const int At = a.heads_total * A;
-  for (int n = wave; n < nb; n += NWAVE) {
-    const float* hrow = a.h + (size_t)(lo + n) * H;
-    const float* trow = a.t + (size_t)(lo + n) * At + (size_t)a.head0 * A;
-    float hreg[JH];
-    float treg[MAX_HEADS][JA > 0 ? JA : 1];
+  // A row's values are requested ONE ROW AHEAD of its arithmetic (round 3): a wave's rows were a chain of "load, then ~200
+  // instructions" with nothing in flight meanwhile -- 25 dependent memory round trips for a 196-node graph on eight waves.
+  // (The requests follow the first use of the current row's registers -- sched_barrier -- so that the wait hipcc puts in front
+  //  of that use cannot include them.)
+  float hnext[JH];
+  float tnext[MAX_HEADS][JA > 0 ? JA : 1];
+  auto request_row = [&](int n) {
+    const int nn = n < nb ? n : (nb > 0 ? nb - 1 : 0);       // past the end: a valid row, never used
+    const float* hrow = a.h + (size_t)(lo + nn) * H;
+    const float* trow = a.t + (size_t)(lo + nn) * At + (size_t)a.head0 * A;
+    // (unconditional loads at clamped, always valid addresses, masked where they are USED: a load under `if (col < H)` is a
+    //  branch around it and a select right behind it a wait -- hipcc then fetched a row's values two at a time, five
+    //  dependent round trips per row)
 #pragma unroll
     for (int j = 0; j < JH; ++j) {
       const int col = lane + 64 * j;
-      hreg[j] = col < H ? hrow[col] : 0.f;
+      hnext[j] = hrow[min(col, H - 1)];                     // (columns >= H: a duplicate, masked where it is used)
     }
     if (JA > 0) {
 #pragma unroll
@@ -93,9 +101,24 @@ __global__ __launch_bounds__(NTHR) void attn_pool_fwd_kernel(PoolArgs a) {
 #pragma unroll
         for (int i = 0; i < (JA > 0 ? JA : 1); ++i) {
           const int j = lane + 64 * i;
-          treg[k][i] = (k < NH && j < A) ? trow[k * A + j] : 0.f;
+          tnext[k][i] = trow[min(k, NH - 1) * A + min(j, A - 1)];
         }
     }
+  };
+  if (wave < nb) request_row(wave);
+  for (int n = wave; n < nb; n += NWAVE) {
+    const float* trow = a.t + (size_t)(lo + n) * At + (size_t)a.head0 * A;
+    float hreg[JH];
+    float treg[MAX_HEADS][JA > 0 ? JA : 1];
+#pragma unroll
+    for (int j = 0; j < JH; ++j) hreg[j] = hnext[j];
+#pragma unroll
+    for (int k = 0; k < MAX_HEADS; ++k)
+#pragma unroll
+      for (int i = 0; i < (JA > 0 ? JA : 1); ++i) treg[k][i] = tnext[k][i];
+    __builtin_amdgcn_sched_barrier(0);
+    request_row(n + NWAVE);
+    __builtin_amdgcn_sched_barrier(0);
     // class-space branch: P[n,c] = W4[c,:] . h[n,:] + b4[c]
     float Pn[MAX_C];
     if (a.W4) {
