@@ -23,7 +23,11 @@ def _rel(got, ref):
 
 
 @pytest.mark.parametrize("M,N,K,act,res", [(1000, 384, 768, 0, "pos"), (700, 1152, 384, 0, None), (513, 384, 384, 0, "full"),
-                                           (300, 1536, 384, 1, None), (2049, 384, 1536, 0, "full"), (5, 128, 64, 0, None)])
+                                           (300, 1536, 384, 1, None), (2049, 384, 1536, 0, "full"), (5, 128, 64, 0, None),
+                                           # M >= 2048, K <= 384: the activation-resident kernel (gemm_f16a.hip) -- the qkv /
+                                           # proj / fc1 shapes, ragged row counts (last tile, a block with fewer tiles), 3-5 K-tiles
+                                           (40001, 1152, 384, 0, None), (33000, 384, 384, 0, "full"), (2100, 1536, 384, 1, None),
+                                           (3999, 384, 384, 0, "pos"), (5000, 128, 192, 0, None), (2048, 256, 320, 0, "full")])
 def test_gemm_f16_matches_fp32_matmul(M, N, K, act, res):
     from isic_hip.lib import call
     g = torch.Generator().manual_seed(M + N + K)
