@@ -30,7 +30,14 @@ _SCALARS = {
 
 
 class IsicHipError(RuntimeError):
-    pass
+    """``code``: the negative ISIC_ERR_* value of a failed C-ABI call (None for host-side errors)."""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
+
+
+ERR_UNSUPPORTED = -2
 
 
 def header_path():
@@ -139,5 +146,5 @@ def call(name, *args, stream=None):
         conv.append(current_stream() if stream is None else stream)
     rc = f(*conv)
     if L.protos[name][0] is ctypes.c_int and rc != 0:
-        raise IsicHipError(f"{name} failed: {ERRORS.get(rc, rc)}")
+        raise IsicHipError(f"{name} failed: {ERRORS.get(rc, rc)}", code=rc)
     return rc

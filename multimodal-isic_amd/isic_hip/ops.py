@@ -11,7 +11,7 @@ import math
 
 import torch
 
-from .lib import IsicHipError, call
+from .lib import ERR_UNSUPPORTED, IsicHipError, call
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 
@@ -224,7 +224,7 @@ class LinearRowsFn(torch.autograd.Function):
                  ws.numel() if ws is not None else 0)
             ctx.gathered = None
         except IsicHipError as e:
-            if "UNSUPPORTED" not in str(e):
+            if e.code != ERR_UNSUPPORTED:
                 raise
             ctx.gathered = xs[rows[:M].long()]
             gemm(ctx.gathered, w, trans_b=True, bias=b, out=y)
@@ -251,7 +251,7 @@ class LinearRowsFn(torch.autograd.Function):
                     call("isic_gemm_f32_rows_ws", 1, 0, N, K, M, g, N, None, xs, K, rows, out, K, None, ACT_NONE, beta, ws,
                          ws.numel() if ws is not None else 0)
                 except IsicHipError as e:
-                    if "UNSUPPORTED" not in str(e):
+                    if e.code != ERR_UNSUPPORTED:
                         raise
                     gemm(g, xs[rows[:M].long()], trans_a=True, out=out, beta=beta)
             dw = None if tgt is not None else out

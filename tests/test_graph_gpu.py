@@ -433,3 +433,41 @@ def test_linear_rows_reads_through_the_index_like_gather_then_linear():
     # a shape the gathering kernel does not take (small M) falls back to gather + linear
     y2 = ops.linear_rows(store, rows_pad, 64, W, b)
     assert_close(y2, y0[:64], rtol=2e-5, atol=2e-5, what="fallback")
+
+
+def test_batch_rows_path_equals_gathered_batch():
+    """GraphStore.batch_rows + GraphMIL(x_rows=...) -- the input projection and its weight gradient read the node features
+    through the batch's row index (isic_csr_batch_assemble's row_index_out -> isic_gemm_f32_rows_ws) -- against GraphStore.batch +
+    GraphMIL on the gathered features: same kernels, same order of summation -> bit-equal probabilities, loss and gradients."""
+    from gnn_models import GraphMIL
+    from isic_hip import train as T
+    gen = torch.Generator().manual_seed(41)
+    G, n, D, k = 80, 196, 768, 8
+    recs = []
+    for i in range(G):
+        src = torch.arange(n).repeat_interleave(k)
+        dst = (src + 1 + torch.randint(0, n - 1, (n * k,), generator=gen)) % n          # no self loops: equal entry counts per graph
+        recs.append({"x": torch.randn(n, D, generator=gen), "edge_index": torch.stack([src, dst]), "y": i % 7})
+    store = T.GraphStore(recs, torch.device(DEV), True, mode="gcn")
+    torch.manual_seed(5)
+    model = GraphMIL(input_dim=D, gnn_type="gcn", gnn_hidden=128, gnn_layers=2, gnn_dropout=0.3, att_dim=64, att_heads=2,
+                     pool_dropout=0.2, classifier_dim=128, classifier_light=True, num_classes=7).to(DEV)
+    model.train()
+    idx = torch.randint(0, G, (64,), generator=gen).to(DEV)
+    y = store.y_dev[idx]
+    params = [p for p in model.parameters()]
+
+    def run(rows_path):
+        model.set_dropout_state(seed=9, step=0)
+        if rows_path:
+            xs, rows, nr, offs, g = store.batch_rows(idx)
+            probs, att, loss = model(xs, offsets=offs, graph=g, labels=y, x_rows=(rows, nr))
+        else:
+            x, offs, g = store.batch(idx)
+            probs, att, loss = model(x, offsets=offs, graph=g, labels=y)
+        return probs.detach().clone(), att.detach().clone(), loss.detach().clone(), torch.autograd.grad(loss, params)
+    pa, aa, la, ga = run(False)
+    pb, ab, lb, gb = run(True)
+    assert torch.equal(pa, pb) and torch.equal(aa, ab) and torch.equal(la, lb)
+    for (name, _), u, v in zip(model.named_parameters(), ga, gb):
+        assert torch.equal(u, v), (name, (u - v).abs().max().item())

@@ -206,3 +206,21 @@ def test_persistent_fp32_gemm(case, beta):
     ref = ref + beta * c0[:, :N].double()
     tol = 2e-6 * max(1.0, K / 1000.0) * (1.0 if act != 2 else 4.0)
     assert_close(c1[:, :N], ref, rtol=tol, atol=tol * float(K) ** 0.5, what=f"persistent gemm {case} beta={beta}")
+
+
+def test_multi_copy_gathers_and_accumulates_many_small_tensors_in_one_launch():
+    """ops.multi_copy (isic_multi_copy_f32): up to 32 (dst, src) pairs per launch, copy or accumulate; 40 pairs exercise the chunking."""
+    from isic_hip import ops
+    g = torch.Generator().manual_seed(3)
+    sizes = [1, 7, 128, 16384, 3, 4097] * 7
+    srcs = [torch.randn(s, generator=g).to(DEV) for s in sizes[:40]]
+    dsts = [torch.randn(s, generator=g).to(DEV) for s in sizes[:40]]
+    before = [d.clone() for d in dsts]
+    ops.multi_copy(dsts, srcs, accumulate=True)
+    for d, b, s_ in zip(dsts, before, srcs):
+        assert torch.equal(d, b + s_)
+    ops.multi_copy(dsts, srcs)
+    for d, s_ in zip(dsts, srcs):
+        assert torch.equal(d, s_)
+    with pytest.raises(Exception):
+        ops.multi_copy(dsts[:2], srcs[:1])
