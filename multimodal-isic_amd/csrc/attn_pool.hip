@@ -258,6 +258,132 @@ __global__ __launch_bounds__(NTHR) void attn_pool_fwd_kernel(PoolArgs a) {
   }
 }
 
+// ---- GraphMIL form (no class-space branch, H <= 128, A <= 128, all heads in one launch) in TWO passes (round 3):
+// the online-softmax kernel above spends ~350 instructions per instance row on ONE wave (four wave reductions, eight
+// exponentials, the running rescale of the pooled sums) and a 196-node graph is 25 such rows in sequence per wave, two waves
+// per SIMD: instruction-bound at 61 us for 256 graphs.  Here
+//   pass 1: a wave per row computes only the heads' scores (attention-hidden row . w3) -> LDS;
+//   softmax over the bag per head in LDS (wave k owns head k), attention weights written out, a[n] = sum_k att[n,k] kept;
+//   pass 2: thread (g, col) sums a[n] * h[n, col] over the rows n = g (mod 4) -- coalesced row reads, no reductions across
+//           lanes -- and the four partial sums meet in LDS in a fixed order.
+// LDS (floats): w3s[NH*A] | sc[max_bag*NH] | asum[max_bag] | zp[4][H] | Ms[4] | Ls[4]
+__global__ __launch_bounds__(NTHR) void attn_pool_fwd2_kernel(PoolArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = a.H, A = a.A, NH = a.heads;
+  float* w3s = smem;
+  float* sc = w3s + NH * A;
+  float* asum = sc + a.max_bag * NH;
+  float* zp = asum + a.max_bag;
+  float* Ms = zp + 4 * H;
+  float* Ls = Ms + MAX_HEADS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  const int64_t lo = a.offsets[b], hi = a.offsets[b + 1];
+  const int nb = (int)(hi - lo);
+  for (int i = tid; i < NH * A; i += NTHR) w3s[i] = a.w3[i];
+  __syncthreads();
+
+  // ---- pass 1: scores.  Lane l holds columns l, l + 64 of every head's slice; the next row's values are requested before
+  //      this row's reductions (unconditional clamped loads, masked where used: see attn_pool_fwd_kernel)
+  const int At = NH * A;
+  // (two rows per wave and iteration: their reductions interleave)
+  float tn[2][MAX_HEADS][2];
+  auto request = [&](int n) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int nr = n + r * NWAVE;
+      const int nn = nr < nb ? nr : (nb > 0 ? nb - 1 : 0);
+      const float* trow = a.t + (size_t)(lo + nn) * At;
+#pragma unroll
+      for (int k = 0; k < MAX_HEADS; ++k)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) tn[r][k][i] = trow[min(k, NH - 1) * A + min(lane + 64 * i, A - 1)];
+    }
+  };
+  if (wave < nb) request(wave);
+  for (int n = wave; n < nb; n += 2 * NWAVE) {
+    float tr[2][MAX_HEADS][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int k = 0; k < MAX_HEADS; ++k) { tr[r][k][0] = tn[r][k][0]; tr[r][k][1] = tn[r][k][1]; }
+    __builtin_amdgcn_sched_barrier(0);
+    request(n + 2 * NWAVE);
+    __builtin_amdgcn_sched_barrier(0);
+    float p[2][MAX_HEADS];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int k = 0; k < MAX_HEADS; ++k) {
+        float q = 0.f;
+        if (k < NH) {
+          if (lane < A) q += tr[r][k][0] * w3s[k * A + lane];
+          if (lane + 64 < A) q += tr[r][k][1] * w3s[k * A + lane + 64];
+        }
+        p[r][k] = q;
+      }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int k = 0; k < MAX_HEADS; ++k) p[r][k] = wave_sum(p[r][k]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int nr = n + r * NWAVE;
+      if (nr < nb && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < MAX_HEADS; ++k) if (k < NH) sc[nr * NH + k] = p[r][k] + a.b3[k];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- softmax over the bag, head k on wave k (fixed lane-strided order, then a fixed reduction tree)
+  if (wave < NH) {
+    const int k = wave;
+    float mx = -INFINITY;
+    for (int n = lane; n < nb; n += 64) mx = fmaxf(mx, sc[n * NH + k]);
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int n = lane; n < nb; n += 64) se += expf(sc[n * NH + k] - mx);
+    se = wave_sum(se);
+    if (lane == 0) { Ms[k] = mx; Ls[k] = se; }
+  }
+  __syncthreads();
+  for (int i = tid; i < nb * NH; i += NTHR) {
+    const int k = i % NH;
+    const float v = expf(sc[i] - Ms[k]) / Ls[k];
+    sc[i] = v;
+    a.att[(size_t)lo * NH + i] = v;
+  }
+  __syncthreads();
+  for (int n = tid; n < nb; n += NTHR) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAX_HEADS; ++k) if (k < NH) s += sc[n * NH + k];
+    asum[n] = s;
+  }
+  __syncthreads();
+  // ---- pass 2: z[col] = (1 / heads) sum_n a[n] h[n, col]
+  if (a.z) {
+    const int col = tid & 127, g = tid >> 7;               // NTHR = 512: four row groups
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (col < H) {
+      const float* hp = a.h + (size_t)lo * H + col;
+      int n = g;
+      for (; n + 12 < nb; n += 16) {                       // four rows of this group in flight
+        const float h0 = hp[(size_t)n * H], h1 = hp[(size_t)(n + 4) * H], h2 = hp[(size_t)(n + 8) * H], h3 = hp[(size_t)(n + 12) * H];
+        s0 += asum[n] * h0; s1 += asum[n + 4] * h1; s2 += asum[n + 8] * h2; s3 += asum[n + 12] * h3;
+      }
+      for (; n < nb; n += 4) s0 += asum[n] * hp[(size_t)n * H];
+      zp[g * H + col] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    if (tid < H) {
+      const float zs = ((zp[tid] + zp[H + tid]) + (zp[2 * H + tid] + zp[3 * H + tid])) / (float)a.heads_total;
+      a.z[(size_t)b * H + tid] = zs;
+    }
+  }
+}
+
 struct PoolBwdArgs {
   const float* h; const float* t; const float* att; const float* P; const float* w3; const float* W4;
   const int64_t* offsets;
@@ -475,6 +601,14 @@ int isic_attn_pool_fwd(const float* h, const float* t, const float* w3, const fl
                                         2 * NWAVE * nh + NWAVE * MAX_C + (size_t)NWAVE * nh * H + 2 * MAX_HEADS +
                                         MAX_HEADS * NWAVE);
     int rc;
+    if (!W4 && z && H <= 128 && A <= 128 && heads <= MAX_HEADS && !patch_logits && !patch_probs && !bag_logits && !bag_probs) {
+      // GraphMIL form: the two-pass kernel
+      const size_t lds2 = sizeof(float) * ((size_t)nh * A + (size_t)max_bag * nh + max_bag + 4 * (size_t)H + 2 * MAX_HEADS);
+      rc = ensure_lds(attn_pool_fwd2_kernel, lds2);
+      if (rc != ISIC_OK) return rc;
+      hipLaunchKernelGGL(attn_pool_fwd2_kernel, dim3(B), dim3(NTHR), lds2, as_stream(stream), a);
+      return isic_launch_status();
+    }
 #define LAUNCH_POOL(JH, JA)                                                                         \
   rc = ensure_lds(attn_pool_fwd_kernel<JH, JA>, lds);                                               \
   if (rc != ISIC_OK) return rc;                                                                     \
