@@ -424,7 +424,39 @@ __global__ __launch_bounds__(NTHR_B) void attn_pool_bwd_kernel(PoolBwdArgs a) {
   float dot[MAX_HEADS];
 #pragma unroll
   for (int k = 0; k < MAX_HEADS; ++k) dot[k] = 0.f;
-  for (int n = wave; n < nb; n += NWAVE_B) {
+  // (GraphMIL form, FAST: two rows per wave and iteration -- their loads are in flight together and their reductions
+  //  interleave; rows n, n + NWAVE_B)
+  int n1 = wave;
+  if (FAST && !a.W4 && a.d_z) {
+    for (; n1 + NWAVE_B < nb; n1 += 2 * NWAVE_B) {
+      float hv[2][2], av[2][MAX_HEADS];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int n = n1 + r * NWAVE_B;
+        const float* hrow = a.h + (size_t)(lo + n) * H;
+        hv[r][0] = hrow[min(lane, H - 1)];
+        hv[r][1] = hrow[min(lane + 64, H - 1)];
+#pragma unroll
+        for (int k = 0; k < MAX_HEADS; ++k) av[r][k] = a.att[(size_t)(lo + n) * NH + min(k, NH - 1)];
+      }
+      float p[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        p[r] = (lane < H ? hv[r][0] * dzs[lane] : 0.f) + (lane + 64 < H ? hv[r][1] * dzs[lane + 64] : 0.f);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) p[r] = wave_sum(p[r]) * inv_heads;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int n = n1 + r * NWAVE_B;
+#pragma unroll
+        for (int k = 0; k < MAX_HEADS; ++k) if (k < NH) {
+          if (lane == 0) da[n * NH + k] = p[r];
+          dot[k] += av[r][k] * p[r];
+        }
+      }
+    }
+  }
+  for (int n = n1; n < nb; n += NWAVE_B) {
     float base = 0.f;
     if (a.d_z) {
       const float* hrow = a.h + (size_t)(lo + n) * H;
