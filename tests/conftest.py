@@ -18,6 +18,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The oracle legs run on torch CPU ops: keep them to the CPUs the container's quota allows (bench.host_threads --
+    the GPU box reports 256 CPUs and a 16-CPU quota, and 128 default threads are throttled to a crawl)."""
+    try:
+        import torch
+        from bench import host_threads
+        torch.set_num_threads(min(torch.get_num_threads(), host_threads()))
+    except Exception:
+        pass
+
+
 def pytest_collection_modifyitems(config, items):
     try:
         import torch
