@@ -73,7 +73,7 @@ KERNEL_CLASSES = (
     ("attn_pool", ("isic_attn_pool",)),
     ("gemm_f16", ("isic_gemm_f16",)),
     ("vit_attention", ("isic_attention_f16",)),
-    ("vit_layernorm_patchify", ("isic_layernorm_f16", "isic_vit_patchify")),
+    ("vit_layernorm_patchify", ("isic_layernorm_f16", "isic_row_stats_f16", "isic_vit_patchify")),
     ("gemm_f32", ("isic_gemm_f32", "isic_colsum")),
 )
 
@@ -325,16 +325,31 @@ def run_vit(args, world, rank, dev):
 
     for i in range(2 + args.warmup):
         step(i)
-    elapsed, host_s, _ = timed_region(step, args, world, dev, timer, ["isic_gemm_f16"], 2 + args.warmup)
+    elapsed, host_s, _ = timed_region(step, args, world, dev, timer, ["isic_gemm_f16", "isic_gemm_f16_stats", "isic_gemm_f16_ln"],
+                                      2 + args.warmup)
     gemm = timer.stop()
     split = instrumented_pass(step, timer, dev, world, start=0)
     if rank != 0:
         return None
+
+    def mnk(name, a):
+        """(M, N, K, residual rows read, fp32 statistics bytes) of one launch of the three product entries"""
+        if name == "isic_gemm_f16":            # (A, W, bias, residual, C, M, N, K, act, residual_rows)
+            M, N, K = a[5], a[6], a[7]
+            return M, N, K, (0 if a[3] is None else (a[9] if a[9] > 0 else M)), 0.0
+        if name == "isic_gemm_f16_stats":      # (A, W, bias, residual, C, row_stats, M, N, K, act, residual_rows): + [M][2N/128][2] fp32
+            M, N, K = a[6], a[7], a[8]
+            return M, N, K, (0 if a[3] is None else (a[10] if a[10] > 0 else M)), 4.0 * M * (2 * N // 128) * 2
+        M, N, K = a[7], a[8], a[9]             # isic_gemm_f16_ln(X, Wg, bias_b, ln_c, ln_stats, ln_parts, C, M, N, K, act, eps)
+        return M, N, K, 0, 4.0 * M * max(a[5], 1) * 2
     ms = sum(m for _n, _a, m in gemm)
-    fl = sum(2.0 * a[5] * a[6] * a[7] for _n, a, _m in gemm)          # (A, W, bias, residual, C, M, N, K, act, residual_rows)
-    # algorithmic bytes of a launch: A[M,K] + W[N,K] + C[M,N] (+ the residual: [M,N], or [residual_rows,N] broadcast) in fp16
-    by = sum(2.0 * (a[5] * a[7] + a[6] * a[7] + a[5] * a[6] + (0 if a[3] is None else (a[9] if a[9] > 0 else a[5]) * a[6]))
-             for _n, a, _m in gemm)
+    fl = sum(2.0 * mnk(n, a)[0] * mnk(n, a)[1] * mnk(n, a)[2] for n, a, _m in gemm)
+    # algorithmic bytes of a launch: A[M,K] + W[N,K] + C[M,N] (+ the residual: [M,N], or [residual_rows,N] broadcast) in fp16,
+    # + the row statistics written / read by the LayerNorm-folded forms
+    by = 0.0
+    for n, a, _m in gemm:
+        M, N, K, rr, sb = mnk(n, a)
+        by += 2.0 * (M * K + N * K + M * N + rr * N) + sb
     achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     line = base_line("images/sec (ViT-S/16 fp16 patch-encoder forward) @ 224x224", "images/s",

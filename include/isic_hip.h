@@ -538,6 +538,22 @@ int isic_add_bf16(uint16_t* a, const uint16_t* b, int64_t n, void* stream);
  * m % residual_rows (the position embedding of the patch projection).  K % 64 == 0, N % 128 == 0, else UNSUPPORTED. */
 int isic_gemm_f16(const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* residual, uint16_t* C,
                   int M, int N, int K, int act, int residual_rows, void* stream);
+/* The pre-norm LayerNorms of a transformer block without their own pass over the activations (round 3).
+ * isic_gemm_f16_stats: isic_gemm_f16 with a residual (act 0) that also writes, per row, the partial sums of its ROUNDED
+ * outputs: row_stats[M][2 * N / 128][2] = (sum, sum of squares) over each 64-column group, i.e. everything a LayerNorm over
+ * the N columns of C needs.  row_stats == NULL: plain isic_gemm_f16.
+ * isic_gemm_f16_ln: C = act(LayerNorm(X) . W^T + bias) computed from the RAW rows X[M,K] (LayerNorm over K, eps):
+ *   C[m][n] = act(rstd_m (sum_k X[m][k] Wg[n][k] - mean_m ln_c[n]) + bias_b[n])
+ * with Wg = W . diag(gamma) (fp16), ln_c[n] = sum_k Wg[n][k], bias_b = bias + W . beta (prepared once per weight set by
+ * the caller; isic_hip/vit.py).  ln_stats: ln_parts == 0 -> [M][2] = (mean, rstd) as isic_row_stats_f16 writes them;
+ * ln_parts > 0 -> [M][ln_parts][2] partial sums as isic_gemm_f16_stats writes them (added in index order; variance =
+ * E[x^2] - mean^2 in fp32, clamped at 0).  K % 64 == 0, K >= 128, N % 128 == 0, else UNSUPPORTED. */
+int isic_gemm_f16_stats(const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* residual, uint16_t* C,
+                        float* row_stats, int M, int N, int K, int act, int residual_rows, void* stream);
+int isic_gemm_f16_ln(const uint16_t* X, const uint16_t* Wg, const float* bias_b, const float* ln_c, const float* ln_stats,
+                     int ln_parts, uint16_t* C, int M, int N, int K, int act, float eps, void* stream);
+/* (mean, rstd) of every row of x[M][N] (fp16, N in {128, 256, 384, 512}) with isic_layernorm_f16's arithmetic. */
+int isic_row_stats_f16(const uint16_t* x, float* stats, int64_t M, int N, float eps, void* stream);
 /* images NCHW fp32 -> rows[N*(H/P)*(W/P)][C*P*P] fp16: the im2col of the P x P / stride P patch projection
  * (Conv2d weight [D][C][P][P] flattened is the Linear weight).  P % 8 == 0, H % P == W % P == 0. */
 int isic_vit_patchify_f16(const float* images_nchw, uint16_t* rows, int N, int C, int H, int W, int P, void* stream);

@@ -27,7 +27,7 @@ constexpr int G_A = GM * 128, G_B = GN * 128, G_STAGE = G_A + G_B;   // bytes pe
 constexpr int G_NST = 3;
 constexpr int G_PER_IT = 6;                 // DMAs per staging wave and K-tile
 constexpr int G_MAXSPB = 4;                 // column slices a block may own
-constexpr int G_LDS = G_NST * G_STAGE + 1024 + G_MAXSPB * 512;       // ring | DMA scratch | the block's biases
+constexpr int G_LDS = G_NST * G_STAGE + 1024 + 2 * G_MAXSPB * 512 + GM * 8;   // ring | DMA scratch | biases | LN column sums | LN row stats
 
 struct GemmF16Args {
   const unsigned short* A;      // [M][K]
@@ -37,6 +37,18 @@ struct GemmF16Args {
   unsigned short* C;            // [M][N]
   int M, N, K, Ktiles, act, res_rows, mtiles, tiles_per_block;
   int spb;                      // consecutive 128-column slices per block (blockIdx.y owns slices y*spb .. +spb)
+  // LayerNorm folded into the product (LNF): A is the RAW input x[M][K] of a LayerNorm over K, W holds W.diag(gamma),
+  // bias holds bias + W.beta, ln_c[n] = sum_k W'[n][k], and
+  //   C[m][n] = act(rstd_m (acc[m][n] - mean_m ln_c[n]) + bias[n])
+  // ln_stats: [M][2] = (mean, rstd) when ln_parts == 0, else [M][ln_parts][2] partial (sum, sum of squares) of the row,
+  // added in index order (what the STATS epilogue of the producing product writes)
+  const float* ln_c;
+  const float* ln_stats;
+  int ln_parts;
+  float ln_eps;
+  // STATS epilogue (SOUT): per row and (slice, wn) the sum and the sum of squares of the 64 rounded outputs this wave
+  // holds -> stats_out[m][2 (N / 128)][2]: the LayerNorm statistics of C without another pass over it
+  float* stats_out;
 };
 
 __device__ __attribute__((aligned(256))) unsigned char g_g16_zero_page[256];
@@ -56,7 +68,7 @@ __device__ __forceinline__ float g16_hi(unsigned w) { return (float)__builtin_bi
 // measured SLOWER (1.01 vs 0.93 ms for fc1; no GELU at all: 0.87 ms -- the layer is bound by its 1.2 GB output).
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
 
-template <int GELU, bool RES>
+template <int GELU, bool RES, bool LNF, bool SOUT>
 __global__ __launch_bounds__(1024) void gemm_f16_kernel(GemmF16Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -132,7 +144,13 @@ __global__ __launch_bounds__(1024) void gemm_f16_kernel(GemmF16Args a) {
     const unsigned boff0 = (unsigned)(G_A + (wn * 64 + fr) * 128 + ((fg ^ (fr & 7)) << 4));
     // the block's biases in LDS (read back per 4 columns in the epilogue: no registers held across the K loop)
     float* bias_all = reinterpret_cast<float*>(smem + off_scr + 1024);
-    if (tid < spb * GN) bias_all[tid] = a.bias ? a.bias[nbase + tid] : 0.f;
+    float* cn_all = bias_all + G_MAXSPB * GN;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2* rowst = reinterpret_cast<f32x2*>(cn_all + G_MAXSPB * GN);     // [GM] (rstd, mean * rstd) of the current row tile
+    if (tid < spb * GN) {
+      bias_all[tid] = a.bias ? a.bias[nbase + tid] : 0.f;
+      if (LNF) cn_all[tid] = a.ln_c[nbase + tid];
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // visible after the first K-tile barrier
 
     int it = 0;
@@ -141,6 +159,7 @@ __global__ __launch_bounds__(1024) void gemm_f16_kernel(GemmF16Args a) {
       const int m0 = (t_begin + tl) * GM;
       const unsigned chan = (unsigned)(nbase + j * GN + wn * 64 + fg * 8);
       const float* bias_lds = bias_all + j * GN;
+      const float* cn_lds = cn_all + j * GN;
       f32x4 acc[4][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -150,6 +169,24 @@ __global__ __launch_bounds__(1024) void gemm_f16_kernel(GemmF16Args a) {
 #pragma unroll 1
       for (int kt = 0; kt < KT; ++kt, ++it) {
         __builtin_amdgcn_s_barrier();
+        if (LNF && kt == 0 && j == 0 && tid < GM) {
+          // every wave is past the previous item's epilogue (it came through this barrier), none reads the new values before
+          // the next one (host: Ktiles >= 2): waves 0-3 finalise the LayerNorm statistics of the tile's 256 rows
+          const int m = min(m0 + tid, a.M - 1);
+          float mean, rstd;
+          if (a.ln_parts == 0) {
+            const f32x2 mr = *reinterpret_cast<const f32x2*>(a.ln_stats + (size_t)m * 2);
+            mean = mr[0]; rstd = mr[1];
+          } else {
+            const f32x2* pp = reinterpret_cast<const f32x2*>(a.ln_stats + (size_t)m * a.ln_parts * 2);
+            float s1 = 0.f, s2 = 0.f;
+            for (int q = 0; q < a.ln_parts; ++q) { const f32x2 v = pp[q]; s1 += v[0]; s2 += v[1]; }
+            const float inv = 1.f / (float)a.K;
+            mean = s1 * inv;
+            rstd = rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + a.ln_eps);
+          }
+          rowst[tid] = (f32x2){rstd, mean * rstd};
+        }
         const unsigned char* st = smem + (it % G_NST) * G_STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -177,68 +214,102 @@ __global__ __launch_bounds__(1024) void gemm_f16_kernel(GemmF16Args a) {
         valid[i] = m < a.M;
         off[i] = (size_t)(valid[i] ? m : 0) * a.N + chan;
       }
-      u32x4 rs[4][2];
-      if (RES) {
+      auto res_row = [&](int i, u32x4 (&r)[2]) {
+        const int m = m0 + wm * 64 + i * 16 + fr;
+        const size_t roff = a.res_rows > 0 ? (size_t)((valid[i] ? m : 0) % a.res_rows) * a.N + chan : off[i];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) r[t] = *reinterpret_cast<const u32x4*>(a.res + roff + t * 32);
+      };
+      u32x4 rs[SOUT ? 1 : 4][2];                       // SOUT emits row by row with the next row's residual in flight
+      if (RES && !SOUT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) res_row(i, rs[i]);
+      }
+      f32x2 rst[4];
+      if (LNF) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rst[i] = rowst[wm * 64 + i * 16 + fr];
+      }
+      float ps1 = 0.f, ps2 = 0.f;                      // SOUT: sums of the row being emitted
+      auto emit = [&](int i, int t, const u32x4& rv) {
+        u32x4 v;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_lds + wn * 64 + fg * 8 + t * 32 + 4 * h);
+          f32x4 c;
+          if (LNF) {
+            const f32x4 cn = *reinterpret_cast<const f32x4*>(cn_lds + wn * 64 + fg * 8 + t * 32 + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c[e] = fmaf(acc[i][2 * t + h][e], rst[i][0], fmaf(-rst[i][1], cn[e], bv[e]));
+          } else {
+            c = acc[i][2 * t + h] + bv;
+          }
+          if (GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c[e] = gelu_erf(c[e]);
+          }
+          if (RES) {
+            const unsigned lo = rv[2 * h], hi = rv[2 * h + 1];
+            c[0] += g16_lo(lo); c[1] += g16_hi(lo); c[2] += g16_lo(hi); c[3] += g16_hi(hi);
+          }
+          const f16x2 p0 = {(_Float16)c[0], (_Float16)c[1]}, p1 = {(_Float16)c[2], (_Float16)c[3]};   // round to nearest even
+          v[2 * h] = __builtin_bit_cast(unsigned, p0);
+          v[2 * h + 1] = __builtin_bit_cast(unsigned, p1);
+          if (SOUT) {                    // sums of the ROUNDED values: what a LayerNorm reading C would see
+            const f16x2 one = {(_Float16)1.f, (_Float16)1.f};
+            ps1 = __builtin_amdgcn_fdot2(p0, one, ps1, false);
+            ps2 = __builtin_amdgcn_fdot2(p0, p0, ps2, false);
+            ps1 = __builtin_amdgcn_fdot2(p1, one, ps1, false);
+            ps2 = __builtin_amdgcn_fdot2(p1, p1, ps2, false);
+          }
+        }
+        if (valid[i]) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.C + off[i] + t * 32));
+      };
+      if (!SOUT) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) emit(i, t, rs[SOUT ? 0 : i][t]);
+      } else {
+        // row by row; the four fg lanes of a row hold its 64 columns of this wave: fixed-order butterfly, lane fg == 0 writes
+        const int parts = 2 * (a.N / GN), part = 2 * ((nbase / GN) + j) + wn;
+        u32x4 cur[2], nxt[2];
+        if (RES) res_row(0, cur);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+          if (RES && i + 1 < 4) res_row(i + 1, nxt);
+          ps1 = ps2 = 0.f;
+          emit(i, 0, cur[0]);
+          emit(i, 1, cur[1]);
+          if (RES) { cur[0] = nxt[0]; cur[1] = nxt[1]; }
+          float s1 = ps1, s2 = ps2;
+          s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+          s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
           const int m = m0 + wm * 64 + i * 16 + fr;
-          const size_t roff = a.res_rows > 0 ? (size_t)((valid[i] ? m : 0) % a.res_rows) * a.N + chan : off[i];
-#pragma unroll
-          for (int t = 0; t < 2; ++t) rs[i][t] = *reinterpret_cast<const u32x4*>(a.res + roff + t * 32);
+          if (fg == 0 && valid[i]) *reinterpret_cast<f32x2*>(a.stats_out + ((size_t)m * parts + part) * 2) = (f32x2){s1, s2};
         }
       }
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          u32x4 v;
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            f32x4 c = acc[i][2 * t + h] + *reinterpret_cast<const f32x4*>(bias_lds + wn * 64 + fg * 8 + t * 32 + 4 * h);
-            if (GELU) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) c[e] = gelu_erf(c[e]);
-            }
-            if (RES) {
-              const unsigned lo = rs[i][t][2 * h], hi = rs[i][t][2 * h + 1];
-              c[0] += g16_lo(lo); c[1] += g16_hi(lo); c[2] += g16_lo(hi); c[3] += g16_hi(hi);
-            }
-            v[2 * h] = g16_pack2(c[0], c[1]);
-            v[2 * h + 1] = g16_pack2(c[2], c[3]);
-          }
-          if (valid[i]) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.C + off[i] + t * 32));
-        }
     }
   }   // MFMA waves
 }
 
-template <int GELU, bool RES>
+template <int GELU, bool RES, bool LNF = false, bool SOUT = false>
 int launch_g16(const GemmF16Args& a, dim3 grid, hipStream_t stream) {
   static IsicPerDeviceOnce once;              // hipFuncSetAttribute is per device (one flag set per template instance)
   if (isic_once_per_device(once, [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<GELU, RES>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<GELU, RES, LNF, SOUT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
       }) != hipSuccess)
     return ISIC_ERR_LAUNCH;
-  hipLaunchKernelGGL((gemm_f16_kernel<GELU, RES>), grid, dim3(1024), G_LDS, stream, a);
+  hipLaunchKernelGGL((gemm_f16_kernel<GELU, RES, LNF, SOUT>), grid, dim3(1024), G_LDS, stream, a);
   return isic_launch_status();
 }
 
-}  // namespace
-
-extern "C" {
-
-int isic_gemm_f16(const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* residual, uint16_t* C,
-                  int M, int N, int K, int act, int residual_rows, void* stream) {
-  ISIC_CHECK_ARG(M >= 0 && N > 0 && K > 0 && (act == 0 || act == 1) && residual_rows >= 0);
-  if (M == 0) return ISIC_OK;
-  ISIC_CHECK_ARG(A && W && C);
-  ISIC_CHECK_ARG(residual || residual_rows == 0);
-  if (N % GN != 0 || K % 64 != 0) return ISIC_ERR_UNSUPPORTED;
+// grid + the fields of `a` that depend on it
+dim3 g16_plan(GemmF16Args& a) {
   const int cus = isic_cu_count();
-  GemmF16Args a;
-  a.A = A; a.W = W; a.bias = bias; a.res = residual; a.C = C;
-  a.M = M; a.N = N; a.K = K; a.Ktiles = K / 64; a.act = act; a.res_rows = residual_rows;
+  const int M = a.M, N = a.N, K = a.K;
+  a.Ktiles = K / 64;
   a.mtiles = (M + GM - 1) / GM;
   const int nslices = N / GN;
   // All N-slices of one row range must share an L2: workgroup w runs on XCD w % 8 and w = x + y * gx, so gx is a multiple
@@ -261,10 +332,52 @@ int isic_gemm_f16(const uint16_t* A, const uint16_t* W, const float* bias, const
   const int gy = nslices / spb;
   a.spb = spb;
   a.tiles_per_block = (a.mtiles + gx - 1) / gx;
-  const dim3 grid(gx, gy);
+  return dim3(gx, gy);
+}
+
+}  // namespace
+
+extern "C" {
+
+int isic_gemm_f16(const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* residual, uint16_t* C,
+                  int M, int N, int K, int act, int residual_rows, void* stream) {
+  return isic_gemm_f16_stats(A, W, bias, residual, C, nullptr, M, N, K, act, residual_rows, stream);
+}
+
+int isic_gemm_f16_stats(const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* residual, uint16_t* C,
+                        float* row_stats, int M, int N, int K, int act, int residual_rows, void* stream) {
+  ISIC_CHECK_ARG(M >= 0 && N > 0 && K > 0 && (act == 0 || act == 1) && residual_rows >= 0);
+  if (M == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(A && W && C);
+  ISIC_CHECK_ARG(residual || residual_rows == 0);
+  if (N % GN != 0 || K % 64 != 0) return ISIC_ERR_UNSUPPORTED;
+  GemmF16Args a;
+  a.A = A; a.W = W; a.bias = bias; a.res = residual; a.C = C;
+  a.M = M; a.N = N; a.K = K; a.act = act; a.res_rows = residual_rows;
+  a.ln_c = nullptr; a.ln_stats = nullptr; a.ln_parts = 0; a.ln_eps = 0.f; a.stats_out = row_stats;
+  const dim3 grid = g16_plan(a);
   hipStream_t s = as_stream(stream);
+  if (row_stats) {                                     // the two producers of a LayerNorm input: residual products
+    if (act == 1 || !residual) return ISIC_ERR_UNSUPPORTED;
+    return launch_g16<0, true, false, true>(a, grid, s);
+  }
   if (act == 1) return residual ? ISIC_ERR_UNSUPPORTED : launch_g16<1, false>(a, grid, s);   // GELU + residual: not a ViT layer
   return residual ? launch_g16<0, true>(a, grid, s) : launch_g16<0, false>(a, grid, s);
+}
+
+int isic_gemm_f16_ln(const uint16_t* X, const uint16_t* Wg, const float* bias_b, const float* ln_c, const float* ln_stats,
+                     int ln_parts, uint16_t* C, int M, int N, int K, int act, float eps, void* stream) {
+  ISIC_CHECK_ARG(M >= 0 && N > 0 && K > 0 && (act == 0 || act == 1) && ln_parts >= 0 && eps >= 0.f);
+  if (M == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(X && Wg && bias_b && ln_c && ln_stats && C);
+  if (N % GN != 0 || K % 64 != 0 || K < 128) return ISIC_ERR_UNSUPPORTED;      // the row statistics need two K-tiles
+  GemmF16Args a;
+  a.A = X; a.W = Wg; a.bias = bias_b; a.res = nullptr; a.C = C;
+  a.M = M; a.N = N; a.K = K; a.act = act; a.res_rows = 0;
+  a.ln_c = ln_c; a.ln_stats = ln_stats; a.ln_parts = ln_parts; a.ln_eps = eps; a.stats_out = nullptr;
+  const dim3 grid = g16_plan(a);
+  hipStream_t s = as_stream(stream);
+  return act == 1 ? launch_g16<1, false, true, false>(a, grid, s) : launch_g16<0, false, true, false>(a, grid, s);
 }
 
 }  // extern "C"

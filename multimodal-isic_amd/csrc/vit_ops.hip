@@ -93,6 +93,37 @@ __global__ __launch_bounds__(256) void layernorm_f16_kernel(const unsigned short
   }
 }
 
+// ---------------------------------------------------------------- LayerNorm statistics only
+// (mean, rstd) per row with the arithmetic of layernorm_f16_kernel, for a LayerNorm folded into the product that consumes it
+// (isic_gemm_f16_ln): reads x once, writes 8 bytes per row.
+template <int LPR, int ACT>
+__global__ __launch_bounds__(256) void row_stats_f16_kernel(const unsigned short* __restrict__ x, float* __restrict__ stats,
+                                                             int64_t M, float eps) {
+  constexpr int N = 8 * ACT;
+  const int lane = threadIdx.x % LPR, rl = threadIdx.x / LPR, rls = 256 / LPR;
+  const bool act = lane < ACT;
+  const int col = (act ? lane : 0) * 8;
+  for (int64_t row = (int64_t)blockIdx.x * rls + rl; row < M; row += (int64_t)gridDim.x * rls) {
+    float f[8];
+    unpack_h8(*reinterpret_cast<const u32x4*>(x + row * N + col), f);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += act ? f[j] : 0.f;
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, LPR);
+    const float mean = s * (1.f / N);
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { f[j] -= mean; v += act ? f[j] * f[j] : 0.f; }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, LPR);
+    if (lane == 0) {
+      stats[row * 2] = mean;
+      stats[row * 2 + 1] = rsqrtf(v * (1.f / N) + eps);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- attention
 // One block (8 waves) per (image, head): T <= 208 tokens, head width 64.  K row-major in LDS ([token][64], 16-byte
 // chunks XOR-swizzled by token & 7), V transposed ([d][token], so that the P.V B-operand is two 8-byte reads); Q is
@@ -269,6 +300,24 @@ int isic_layernorm_f16(const uint16_t* x, const float* gamma, const float* beta,
   else if (N == 512) { LAUNCH_LN16(64, 64); }
   else return ISIC_ERR_UNSUPPORTED;
 #undef LAUNCH_LN16
+  return isic_launch_status();
+}
+
+int isic_row_stats_f16(const uint16_t* x, float* stats, int64_t M, int N, float eps, void* stream) {
+  ISIC_CHECK_ARG(M >= 0 && N > 0);
+  if (M == 0) return ISIC_OK;
+  ISIC_CHECK_ARG(x && stats);
+  int64_t g;
+#define LAUNCH_RS16(LPR, ACT)                                                                                    \
+  g = (M + (256 / LPR) * 4 - 1) / ((256 / LPR) * 4);                                                             \
+  if (g > 8192) g = 8192;                                                                                        \
+  hipLaunchKernelGGL((row_stats_f16_kernel<LPR, ACT>), dim3((int)g), dim3(256), 0, as_stream(stream), x, stats, M, eps)
+  if (N == 128) { LAUNCH_RS16(16, 16); }
+  else if (N == 256) { LAUNCH_RS16(32, 32); }
+  else if (N == 384) { LAUNCH_RS16(64, 48); }
+  else if (N == 512) { LAUNCH_RS16(64, 64); }
+  else return ISIC_ERR_UNSUPPORTED;
+#undef LAUNCH_RS16
   return isic_launch_status();
 }
 

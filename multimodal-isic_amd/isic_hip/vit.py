@@ -8,6 +8,13 @@ consumes the 196 patch tokens only, `save_latent.py:56-60,77`).  Inference only,
 Every layer is one launch of the C ABI: `isic_vit_patchify_f16`, `isic_gemm_f16` (bias, GELU, residual / position
 embedding fused into the epilogue), `isic_layernorm_f16`, `isic_attention_f16`.  The residual stream and all
 activations are fp16 in HBM ([N*196, 384] rows), arithmetic is fp32 inside the kernels.  No CPU fallback.
+
+``fold_layernorm`` (default True, round 3): the two pre-norm LayerNorms of a block have no pass of their own.  With
+W' = W diag(gamma), c = W' 1, b' = b + W beta:   LN(x) W^T + b = rstd (x W'^T - mean c) + b'   -- the product reads the RAW
+residual stream (`isic_gemm_f16_ln`) and applies the row's (mean, rstd) in its epilogue; the row sums those need come
+out of the epilogue of the product that WROTE the stream (`isic_gemm_f16_stats`: patch projection, attn.proj, mlp.fc2).
+``"stats"`` keeps a statistics-only pass (`isic_row_stats_f16`, LayerNorm's two-pass arithmetic) in place of the epilogue
+sums; ``False`` is the layer-by-layer form above.
 """
 from __future__ import annotations
 
@@ -22,8 +29,12 @@ _F16 = torch.float16
 
 
 class ViTSmallEncoder(nn.Module):
-    def __init__(self, img_size=224, patch=16, in_ch=3, dim=384, depth=12, heads=6, mlp_ratio=4, seed=0):
+    def __init__(self, img_size=224, patch=16, in_ch=3, dim=384, depth=12, heads=6, mlp_ratio=4, seed=0,
+                 fold_layernorm=True):
         super().__init__()
+        if fold_layernorm not in (True, False, "stats"):
+            raise ValueError("fold_layernorm: True, False or 'stats'")
+        self.fold_layernorm = fold_layernorm
         if dim % 128 != 0 or dim // heads != 64 or patch % 8 != 0 or img_size % patch != 0:
             raise ValueError("ViTSmallEncoder: dim % 128 == 0, head width 64, patch % 8 == 0, img_size % patch == 0")
         self.img_size, self.patch, self.in_ch, self.dim, self.depth, self.heads = img_size, patch, in_ch, dim, depth, heads
@@ -117,6 +128,16 @@ class ViTSmallEncoder(nn.Module):
                 w[n] = p.to(_F16).contiguous()
             else:
                 w[n] = p.float().contiguous()                                      # biases, LayerNorm affine: fp32
+        # LayerNorm folded into the product that follows it (module docstring): W' fp16, c from the ROUNDED W' (it has to
+        # cancel what the MFMAs sum), b' fp32
+        for i in range(self.depth):
+            for norm, lin in ((f"blocks.{i}.norm1", f"blocks.{i}.attn.qkv"), (f"blocks.{i}.norm2", f"blocks.{i}.mlp.fc1")):
+                W = self._get(lin + ".weight").detach().float()
+                gamma, beta = w[norm + ".weight"], w[norm + ".bias"]
+                Wg = (W * gamma[None, :]).to(_F16).contiguous()
+                w[lin + ".ln_weight"] = Wg
+                w[lin + ".ln_c"] = Wg.float().sum(dim=1).contiguous()
+                w[lin + ".ln_bias"] = (w[lin + ".bias"] + W @ beta).contiguous()
         self._w16, self._w16_key = w, key
         return w
 
@@ -136,22 +157,46 @@ class ViTSmallEncoder(nn.Module):
         rows = torch.empty((M, K0), device=dev, dtype=_F16)
         call("isic_vit_patchify_f16", x_in, rows, N, self.in_ch, self.img_size, self.img_size, self.patch)
         x = torch.empty((M, D), device=dev, dtype=_F16)
-        call("isic_gemm_f16", rows, w["patch_embed.proj.weight"], w["patch_embed.proj.bias"], w["pos_embed"], x, M, D, K0, 0, T)
-        del rows
-        h = torch.empty((M, D), device=dev, dtype=_F16)
+        fold = self.fold_layernorm
+        eps = 1e-6
+        h = torch.empty((M, D), device=dev, dtype=_F16) if fold is False else None
         qkv = torch.empty((M, 3 * D), device=dev, dtype=_F16)
         att = torch.empty((M, D), device=dev, dtype=_F16)
         hid = torch.empty((M, self.mlp), device=dev, dtype=_F16)
         x2 = torch.empty_like(x)
+        # row statistics of x / x2: partial sums per 64-column group out of the producing epilogue (fold True), or
+        # (mean, rstd) from a statistics-only pass ("stats")
+        parts = 2 * D // 128 if fold is True else 0
+        st = torch.empty((M, max(parts, 1), 2), device=dev, dtype=torch.float32) if fold is not False else None
+        st2 = torch.empty_like(st) if fold is not False else None
+
+        def linear_res(a, name, res, out, stats, K, res_rows=0):
+            """out = a . W^T + b + res; the LayerNorm statistics of out on the way when the next product wants them"""
+            if fold is True:
+                call("isic_gemm_f16_stats", a, w[name + ".weight"], w[name + ".bias"], res, out, stats, M, D, K, 0, res_rows)
+            else:
+                call("isic_gemm_f16", a, w[name + ".weight"], w[name + ".bias"], res, out, M, D, K, 0, res_rows)
+                if fold == "stats":
+                    call("isic_row_stats_f16", out, stats, M, D, eps)
+
+        def linear_ln(xin, stats, norm, name, out, Nout, act):
+            """out = act(LayerNorm(xin) . W^T + b)"""
+            if fold is False:
+                call("isic_layernorm_f16", xin, w[norm + ".weight"], w[norm + ".bias"], h, None, M, D, eps)
+                call("isic_gemm_f16", h, w[name + ".weight"], w[name + ".bias"], None, out, M, Nout, D, act, 0)
+            else:
+                call("isic_gemm_f16_ln", xin, w[name + ".ln_weight"], w[name + ".ln_bias"], w[name + ".ln_c"], stats, parts, out,
+                     M, Nout, D, act, eps)
+
+        linear_res(rows, "patch_embed.proj", w["pos_embed"], x, st, K0, res_rows=T)
+        del rows
         for i in range(self.depth if depth is None else depth):
             b = f"blocks.{i}"
-            call("isic_layernorm_f16", x, w[f"{b}.norm1.weight"], w[f"{b}.norm1.bias"], h, None, M, D, 1e-6)
-            call("isic_gemm_f16", h, w[f"{b}.attn.qkv.weight"], w[f"{b}.attn.qkv.bias"], None, qkv, M, 3 * D, D, 0, 0)
+            linear_ln(x, st, f"{b}.norm1", f"{b}.attn.qkv", qkv, 3 * D, 0)
             call("isic_attention_f16", qkv, att, N, T, H, D // H)
-            call("isic_gemm_f16", att, w[f"{b}.attn.proj.weight"], w[f"{b}.attn.proj.bias"], x, x2, M, D, D, 0, 0)
-            call("isic_layernorm_f16", x2, w[f"{b}.norm2.weight"], w[f"{b}.norm2.bias"], h, None, M, D, 1e-6)
-            call("isic_gemm_f16", h, w[f"{b}.mlp.fc1.weight"], w[f"{b}.mlp.fc1.bias"], None, hid, M, self.mlp, D, 1, 0)
-            call("isic_gemm_f16", hid, w[f"{b}.mlp.fc2.weight"], w[f"{b}.mlp.fc2.bias"], x2, x, M, D, self.mlp, 0, 0)
+            linear_res(att, f"{b}.attn.proj", x, x2, st2, D)
+            linear_ln(x2, st2, f"{b}.norm2", f"{b}.mlp.fc1", hid, self.mlp, 1)
+            linear_res(hid, f"{b}.mlp.fc2", x2, x, st, self.mlp)
         out = torch.empty((M, D), device=dev, dtype=torch.float32)
         call("isic_layernorm_f16", x, w["norm.weight"], w["norm.bias"], None, out, M, D, 1e-6)
         return out.view(N, T, D)

@@ -79,6 +79,79 @@ def test_layernorm_f16(N):
     assert float((y.float().cpu() - ref).abs().max()) <= 2.0 ** -10 * float(ref.abs().max()) + 1e-4
 
 
+def _ln_fold(W, gamma, beta, b):
+    """what isic_hip/vit.py prepares once per weight set: W' = W diag(gamma) in fp16, c = W' 1, b' = b + W beta"""
+    Wg = (W.float() * gamma[None, :]).to(F16)
+    return Wg, Wg.float().sum(dim=1), b + W.float() @ beta
+
+
+@pytest.mark.parametrize("M,N,K,act", [(1000, 1152, 384, 0), (2100, 1536, 384, 1), (513, 128, 128, 0), (40001, 384, 384, 0),
+                                       (777, 256, 512, 0), (5, 128, 256, 1)])
+def test_gemm_f16_ln_matches_layernorm_then_matmul(M, N, K, act):
+    """LayerNorm folded into the product: C = act(LN(x) W^T + b) from the RAW rows and their (mean, rstd)"""
+    from isic_hip.lib import call
+    g = torch.Generator().manual_seed(M + N + K + act)
+    x = (torch.randn(M, K, generator=g) * (1.0 + torch.rand(M, 1, generator=g) * 3) + torch.randn(M, 1, generator=g) * 2).to(F16)
+    gamma, beta = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.2
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(F16)
+    b = torch.randn(N, generator=g) * 0.1
+    ref = torch.nn.functional.layer_norm(x.float(), (K,), gamma, beta, 1e-6) @ W.float().t() + b
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    Wg, c, bb = _ln_fold(W, gamma, beta, b)
+    xd = x.to(DEV)
+    st = torch.full((M, 2), float("nan"), device=DEV)
+    call("isic_row_stats_f16", xd, st, M, K, 1e-6)
+    mean = x.float().mean(dim=1)
+    rstd = torch.rsqrt(x.float().var(dim=1, unbiased=False) + 1e-6)
+    assert float((st[:, 0].cpu() - mean).abs().max()) <= 1e-5 * float(mean.abs().max()) + 1e-6
+    assert float((st[:, 1].cpu() / rstd - 1).abs().max()) <= 1e-5
+    C = torch.full((M, N), float("nan"), device=DEV, dtype=F16)
+    call("isic_gemm_f16_ln", xd, Wg.to(DEV), bb.to(DEV), c.to(DEV), st, 0, C, M, N, K, act, 1e-6)
+    got = C.float().cpu()
+    assert bool(torch.isfinite(got).all())
+    err = (got - ref).abs()
+    tol = 2.0 ** -10 * ref.abs() + 3e-3          # fp16 result + W' rounded once more than W (2^-12 relative per weight)
+    assert bool((err <= tol).all()), float((err - tol).max())
+
+
+@pytest.mark.parametrize("M,N,K,res", [(3000, 384, 768, "pos"), (2049, 384, 1536, "full"), (515, 128, 64, "full")])
+def test_gemm_f16_stats_writes_the_row_sums_of_its_rounded_output(M, N, K, res):
+    """the statistics epilogue: same C as isic_gemm_f16, bit for bit, + per 64-column group (sum, sum of squares) of it; a
+    LayerNorm-folded product fed with those partial sums == one fed with isic_row_stats_f16's (mean, rstd)"""
+    from isic_hip.lib import call
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).to(F16).to(DEV)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(F16).to(DEV)
+    b = (torch.randn(N, generator=g) * 0.1).to(DEV)
+    rr = 196 if res == "pos" else 0
+    R = (torch.randn(rr if rr else M, N, generator=g) * 2 + 1).to(F16).to(DEV)
+    C0 = torch.empty(M, N, device=DEV, dtype=F16)
+    C1 = torch.empty_like(C0)
+    parts = 2 * N // 128
+    st = torch.full((M, parts, 2), float("nan"), device=DEV)
+    call("isic_gemm_f16", A, W, b, R, C0, M, N, K, 0, rr)
+    call("isic_gemm_f16_stats", A, W, b, R, C1, st, M, N, K, 0, rr)
+    assert torch.equal(C0.view(torch.int16), C1.view(torch.int16))
+    grp = C1.double().view(M, parts, 64)
+    assert float((st[:, :, 0].double() - grp.sum(-1)).abs().max()) <= 1e-5 * float(grp.abs().sum(-1).max())
+    assert float((st[:, :, 1].double() - (grp * grp).sum(-1)).abs().max()) <= 1e-5 * float((grp * grp).sum(-1).max())
+    from isic_hip.lib import IsicHipError
+    with pytest.raises(IsicHipError):
+        call("isic_gemm_f16_stats", A, W, b, None, C1, st, M, N, K, 0, 0)          # statistics come with a residual product only
+    if N >= 128 and N in (128, 256, 384, 512):
+        g2 = torch.Generator().manual_seed(5)
+        gamma, beta = torch.rand(N, generator=g2) + 0.5, torch.randn(N, generator=g2) * 0.2
+        W2 = (torch.randn(256, N, generator=g2) / math.sqrt(N)).to(F16)
+        Wg, c, bb = _ln_fold(W2, gamma, beta, torch.zeros(256))
+        st2 = torch.empty(M, 2, device=DEV)
+        call("isic_row_stats_f16", C1, st2, M, N, 1e-6)
+        Da, Db = torch.empty(M, 256, device=DEV, dtype=F16), torch.empty(M, 256, device=DEV, dtype=F16)
+        call("isic_gemm_f16_ln", C1, Wg.to(DEV), bb.to(DEV), c.to(DEV), st2, 0, Da, M, 256, N, 0, 1e-6)
+        call("isic_gemm_f16_ln", C1, Wg.to(DEV), bb.to(DEV), c.to(DEV), st, parts, Db, M, 256, N, 0, 1e-6)
+        assert float((Da.float() - Db.float()).abs().max()) <= 2.0 ** -9 * float(Da.float().abs().max()) + 1e-3
+
+
 @pytest.mark.parametrize("T,heads,n", [(196, 6, 3), (4, 6, 2), (50, 2, 5), (208, 1, 2), (17, 3, 1)])
 def test_attention_f16(T, heads, n):
     from isic_hip.lib import call
@@ -107,11 +180,18 @@ def test_patchify_matches_unfold():
     assert torch.equal(rows.cpu().view(torch.int16), ref.view(torch.int16))
 
 
-def _encoder_and_params(img):
+def _encoder_and_params(img, fold=True, affine=False):
     from isic_hip.vit import ViTSmallEncoder
     from oracle import vit as ov
     p = ov.init_params(5, img=img)
-    enc = ViTSmallEncoder(img_size=img).to(DEV)
+    if affine:                       # LayerNorm weights / biases away from (1, 0): what a trained checkpoint carries
+        g = torch.Generator().manual_seed(17)
+        for k in p:
+            if "norm" in k and k.endswith(".weight"):
+                p[k] = p[k] * (0.5 + torch.rand(p[k].shape, generator=g))
+            elif "norm" in k and k.endswith(".bias"):
+                p[k] = p[k] + 0.2 * torch.randn(p[k].shape, generator=g)
+    enc = ViTSmallEncoder(img_size=img, fold_layernorm=fold).to(DEV)
     enc.load_state_dict(p)
     return enc, p, ov
 
@@ -129,9 +209,12 @@ def test_state_dict_has_timm_names_and_is_frozen():
         enc.run_tokens(torch.zeros(1, 3, 32, 32))             # CPU tensor: no fallback
 
 
-@pytest.mark.parametrize("img,n", [(32, 5), (224, 3)])
-def test_encoder_tokens_match_oracle(img, n):
-    enc, p, ov = _encoder_and_params(img)
+@pytest.mark.parametrize("img,n,fold,affine", [(32, 5, True, False), (224, 3, True, False), (224, 3, True, True), (32, 5, "stats", True),
+                                               (224, 2, False, True), (32, 5, False, False)])
+def test_encoder_tokens_match_oracle(img, n, fold, affine):
+    """fold: the LayerNorms inside the products (statistics out of the producing epilogue) / with a statistics-only pass /
+    as passes of their own -- all three against the same oracle at the same tolerances"""
+    enc, p, ov = _encoder_and_params(img, fold, affine)
     g = torch.Generator().manual_seed(11)
     x = torch.randn(n, 3, img, img, generator=g)
     got = enc.run_tokens(x.to(DEV)).cpu()
