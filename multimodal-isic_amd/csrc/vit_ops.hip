@@ -205,23 +205,29 @@ __global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_f16_kernel(const u
     }
     if (qt + AT_WAVES < qtiles) load_q(qt + AT_WAVES, qf);            // next tile's queries under the softmax
     // ---- softmax over the keys of query fr (base-2 exponent, scale folded in); keys >= T masked out
+    // The softmax is what this kernel spends its issue slots on (52 values per lane and tile against 54 MFMAs): the maximum is
+    // taken over the RAW scores (the scale is positive), scale and shift are one FMA, the exponential is the bare v_exp_f32
+    // (results below 2^-126 flush to zero: they are rounded to fp16 next), and only a key tile that crosses T is masked.
     float mx = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < 13; ++kt)
+    for (int kt = 0; kt < 13; ++kt) {
+      if (kt * 16 + 16 > T) {                                         // wave-uniform: at most the last tiles
+        asm volatile("" ::: "memory");                                // a real branch: if-converted, it costs 2 selects per value
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + fg * 4 + r;
-        s[kt][r] = key < T ? s[kt][r] * scale_log2e : -INFINITY;
-        mx = fmaxf(mx, s[kt][r]);
+        for (int r = 0; r < 4; ++r) s[kt][r] = kt * 16 + fg * 4 + r < T ? s[kt][r] : -INFINITY;
       }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float shift = -mx * scale_log2e;
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 13; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        s[kt][r] = exp2f(s[kt][r] - mx);
+        s[kt][r] = __builtin_amdgcn_exp2f(fmaf(s[kt][r], scale_log2e, shift));
         sum += s[kt][r];
       }
     sum += __shfl_xor(sum, 16, 64);
