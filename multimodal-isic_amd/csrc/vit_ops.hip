@@ -125,25 +125,33 @@ __global__ __launch_bounds__(256) void row_stats_f16_kernel(const unsigned short
 }
 
 // ---------------------------------------------------------------- attention
-// One block (8 waves) per (image, head): T <= 208 tokens, head width 64.  K row-major in LDS ([token][64], 16-byte
-// chunks XOR-swizzled by token & 7), V transposed ([d][token], so that the P.V B-operand is two 8-byte reads); Q is
-// never staged: a wave reads the two 16-byte fragments of its 16 queries straight from global memory.  72 KB of LDS:
-// two blocks per CU, so one block's loads overlap the other's arithmetic.  A wave owns query tiles of 16: S^T = K.Q^T on
+// One block (8 waves) per (image, head): T <= 208 tokens, head width 64.  K and V row-major in LDS ([token][64] = 128-byte
+// rows; 16-byte chunks XOR-swizzled by token & 7 for K, by (token >> 1) & 7 for V); Q is never staged: a wave reads the two
+// 16-byte fragments of its 16 queries straight from global memory.  54 KB of LDS: two blocks per CU (register-limited), so
+// one block's loads overlap the other's arithmetic.  A wave owns query tiles of 16: S^T = K.Q^T on
 // v_mfma_f32_16x16x32_f16 (13 key tiles x 2 k-steps; a lane then holds, for ITS query l % 16, the scores of keys
 // 16t + 4(l/16) + r), softmax over keys = in-lane over the 52 values + two xor shuffles; the probabilities are already
-// in the A-operand position of O = P.V up to a permutation of the contraction index, which is applied to V's rows
-// instead (k-slot 8(l/16) + e <-> key 32u + 16(e/4) + 4(l/16) + e%4).
-constexpr int AT_TMAX = 208, AT_KPAD = 224, AT_VPITCH = 232;         // tokens padded to 13 x 16 (scores) / 7 x 32 (P.V)
+// in operand position of P.V up to a permutation of the contraction index (k-slot 8(l/16) + e <-> key
+// 32u + 16(e/4) + 4(l/16) + e%4), which the V fragments follow.
+// Round 3: O^T = V^T.P^T instead of O = P.V.  The V^T fragment (head dimension x keys) comes out of the row-major V with
+// ds_read_b64_tr_b16 -- a 16-lane group addresses 4 keys x 16 head dimensions and each lane receives ONE dimension's four
+// keys -- so V is staged with 16-byte writes like K (it was 32 ds_write_b16 per thread into a transposed copy); the head
+// dimensions a group addresses are chosen so that a lane ends with EIGHT CONSECUTIVE dimensions of its own query
+// (d = 32 (jd >> 1) + 8 (l / 16) + 4 (jd & 1) + r): the result is normalised with the lane's own 1 / sum and leaves in two
+// 16-byte stores, no LDS transpose, no shuffles.
+constexpr int AT_TMAX = 208, AT_KPAD = 224;                          // tokens padded to 13 x 16 (scores) / 7 x 32 (P.V)
 constexpr int AT_WAVES = 8;
-constexpr int AT_K = AT_TMAX * 128, AT_V = 64 * AT_VPITCH * 2, AT_O = AT_WAVES * 16 * 128;
-constexpr int AT_LDS = AT_K + AT_V + AT_O;
+constexpr int AT_K = AT_TMAX * 128, AT_V = AT_KPAD * 128;
+constexpr int AT_LDS = AT_K + AT_V;
 
 __global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_f16_kernel(const unsigned short* __restrict__ qkv,
                                                                           unsigned short* __restrict__ out, int T,
                                                                           int heads, float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Ks = smem;
-  unsigned short* Vt = reinterpret_cast<unsigned short*>(smem + AT_K);
+  unsigned char* Vs = smem + AT_K;
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+  const unsigned vs0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)Vs;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int img = blockIdx.x / heads, head = blockIdx.x - img * heads;
   const int D = heads * 64, ld = 3 * D;                               // qkv row: [q heads*64 | k heads*64 | v heads*64]
@@ -178,18 +186,21 @@ __global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_f16_kernel(const u
   for (int u = 0; u < KV_PER; ++u) {
     const int idx = tid + u * AT_WAVES * 64, t = idx >> 3, ch = idx & 7;
     if (t < AT_TMAX) *reinterpret_cast<u32x4*>(Ks + t * 128 + ((ch ^ (t & 7)) << 4)) = kr[u];
-    if (t < AT_KPAD) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const unsigned w = vr[u][e];
-        Vt[(ch * 8 + 2 * e) * AT_VPITCH + t] = (unsigned short)(w & 0xFFFFu);
-        Vt[(ch * 8 + 2 * e + 1) * AT_VPITCH + t] = (unsigned short)(w >> 16);
-      }
-    }
+    if (t < AT_KPAD) *reinterpret_cast<u32x4*>(Vs + t * 128 + ((ch ^ ((t >> 1) & 7)) << 4)) = vr[u];
   }
   __syncthreads();
 
-  unsigned char* Os = smem + AT_K + AT_V + wave * (16 * 128);
+  // V^T fragment addresses: lane (fg, fq, fp) of a 16-lane group reads key 4fg + fq (+ 32u, + 16 for the upper half), the four
+  // head dimensions 32 (jd >> 1) + 8 fp + 4 (jd & 1) + {0..3}: chunk (jd >> 1) * 4 + fp, swizzled by (key >> 1) & 7 (the
+  // same for every u and both halves), byte (jd & 1) * 8 inside it.  16 keys x 4 x 8 bytes per instruction spread over half
+  // of the banks evenly: the b64 rate.
+  unsigned voff[4];
+  {
+    const int fq = fr >> 2, fp = fr & 3, key = 4 * fg + fq, hsw = (key >> 1) & 7;
+#pragma unroll
+    for (int jd = 0; jd < 4; ++jd)
+      voff[jd] = vs0 + (unsigned)(key * 128 + ((((jd >> 1) * 4 + fp) ^ hsw) << 4) + (jd & 1) * 8);
+  }
   for (int qt = wave; qt < qtiles; qt += AT_WAVES) {
     // ---- S^T tile row: keys x this tile's 16 queries
     f32x4 s[13];
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_f16_kernel(const u
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.f / sum;                                      // of query fr
 
-    // ---- O = P.V: 7 key blocks of 32 (tiles 2u, 2u+1; tile 13 does not exist: zeros), 4 head-width tiles of 16
+    // ---- O^T = V^T.P^T: 7 key blocks of 32 (tiles 2u, 2u+1; tile 13 does not exist: zeros), 4 head-dimension tiles of 16
     f32x4 o[4];
 #pragma unroll
     for (int jd = 0; jd < 4; ++jd) o[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -248,30 +259,26 @@ __global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_f16_kernel(const u
       }
 #pragma unroll
       for (int jd = 0; jd < 4; ++jd) {
-        const unsigned short* vrow = Vt + (jd * 16 + fr) * AT_VPITCH + u * 32 + fg * 4;
-        const f16x4 lo = *reinterpret_cast<const f16x4*>(vrow), hi = *reinterpret_cast<const f16x4*>(vrow + 16);
-        const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        o[jd] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf, vf, o[jd], 0, 0, 0);       // D[query 4fg+r][d fr]
+        s16x8_t t;
+        t.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(size_t)(voff[jd] + (unsigned)(u * 32 * 128)));
+        t.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(size_t)(voff[jd] + (unsigned)(u * 32 * 128 + 16 * 128)));
+        o[jd] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, t), pf, o[jd], 0, 0, 0);   // D[d-slot 4fg+r][query fr]
       }
     }
-    // ---- normalise (the sum of query q lives in every lane with l % 16 == q), transpose through LDS, 16-byte stores
+    // ---- normalise with the lane's own 1 / sum; dimensions 32t' + 8fg + {0..7} of query fr: two 16-byte stores
+    const int q = qt * 16 + fr;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float iv = __shfl(inv, fg * 4 + r, 64);
+    for (int tp = 0; tp < 2; ++tp) {
+      u32x4 v;
 #pragma unroll
-      for (int jd = 0; jd < 4; ++jd)
-        *reinterpret_cast<unsigned short*>(Os + (fg * 4 + r) * 128 + (jd * 16 + fr) * 2) =
-            __builtin_bit_cast(unsigned short, (_Float16)(o[jd][r] * iv));
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 c = o[2 * tp + h] * inv;
+        const f16x2 p0 = {(_Float16)c[0], (_Float16)c[1]}, p1 = {(_Float16)c[2], (_Float16)c[3]};
+        v[2 * h] = __builtin_bit_cast(unsigned, p0);
+        v[2 * h + 1] = __builtin_bit_cast(unsigned, p1);
+      }
+      if (q < T) *reinterpret_cast<u32x4*>(out + ((size_t)img * T + q) * D + head * 64 + 32 * tp + 8 * fg) = v;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // wave-private tile: no barrier needed
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int ql = h * 8 + (lane >> 3), ch = lane & 7, q = qt * 16 + ql;
-      if (q < T)
-        *reinterpret_cast<u32x4*>(out + ((size_t)img * T + q) * D + head * 64 + ch * 8) =
-            *reinterpret_cast<const u32x4*>(Os + ql * 128 + ch * 16);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // Os is rewritten by the next tile
   }
 }
 
