@@ -92,6 +92,28 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
 // ---------------------------------------------------------------- wave reductions (64 lanes)
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits for every
 // global store the wave has in flight -- a full memory round trip when it follows an epilogue's output stores.
+// Full 128-byte lines per store instruction for the register-only tile epilogues (round 3, tests/probes/probe_rw.hip: a
+// nontemporal 16-byte store instruction whose lanes cover 64 bytes of a row streams at 3.2 TB/s, one that covers whole 128-byte
+// lines at 5.4).  After the MFMAs lane (fg, fr) of a wave owns, of row fr, the 16 bytes at column group 8 fg of BOTH 64-byte
+// halves t = 0, 1 of a 128-byte line, so an instruction that stores one half writes 16 rows x 64 B.  Adjacent lanes (rows fr,
+// fr ^ 1; same fg) swap one vector instead: the even lane keeps its t = 0 part and receives the odd row's t = 0 part, the odd
+// lane keeps t = 1 and receives the even row's t = 1.  Then
+//   store A: data `a` at (row fr & ~1, half fr & 1)      store B: data `b` at (row fr | 1, half fr & 1)
+// and each instruction writes 8 rows x 128 B.  Four v_mov_dpp (quad_perm 1,0,3,2) and twelve selects per pair of vectors.
+__device__ __forceinline__ void isic_pair_rows(const u32x4& v0, const u32x4& v1, bool odd, u32x4& a, u32x4& b) {
+  u32x4 recv;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned send = odd ? v0[e] : v1[e];
+    recv[e] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, false);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    a[e] = odd ? recv[e] : v0[e];
+    b[e] = odd ? v1[e] : recv[e];
+  }
+}
+
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }

@@ -220,18 +220,16 @@ __global__ __launch_bounds__(1024) void gemm_f16_kernel(GemmF16Args a) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) r[t] = *reinterpret_cast<const u32x4*>(a.res + roff + t * 32);
       };
-      u32x4 rs[SOUT ? 1 : 4][2];                       // SOUT emits row by row with the next row's residual in flight
-      if (RES && !SOUT) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) res_row(i, rs[i]);
-      }
       f32x2 rst[4];
       if (LNF) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) rst[i] = rowst[wm * 64 + i * 16 + fr];
       }
+      // A row is emitted whole (both 64-byte halves t), then adjacent lanes swap one half (isic_pair_rows) so that every store
+      // instruction writes 8 rows x 128 B instead of 16 rows x 64 B: the stores of this epilogue stream at 5.4 instead of
+      // 3.2 TB/s (tests/probes/probe_rw.hip) -- they were 40-50 % of a launch.
       float ps1 = 0.f, ps2 = 0.f;                      // SOUT: sums of the row being emitted
-      auto emit = [&](int i, int t, const u32x4& rv) {
+      auto make = [&](int i, int t, const u32x4& rv) -> u32x4 {
         u32x4 v;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -263,25 +261,28 @@ __global__ __launch_bounds__(1024) void gemm_f16_kernel(GemmF16Args a) {
             ps2 = __builtin_amdgcn_fdot2(p1, p1, ps2, false);
           }
         }
-        if (valid[i]) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.C + off[i] + t * 32));
+        return v;
       };
-      if (!SOUT) {
+      const bool odd = fr & 1;
+      const int parts = 2 * (a.N / GN), part = 2 * ((nbase / GN) + j) + wn;
+      u32x4 cur[2] = {}, nxt[2] = {};
+      if (RES) res_row(0, cur);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) emit(i, t, rs[SOUT ? 0 : i][t]);
-      } else {
-        // row by row; the four fg lanes of a row hold its 64 columns of this wave: fixed-order butterfly, lane fg == 0 writes
-        const int parts = 2 * (a.N / GN), part = 2 * ((nbase / GN) + j) + wn;
-        u32x4 cur[2], nxt[2];
-        if (RES) res_row(0, cur);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (RES && i + 1 < 4) res_row(i + 1, nxt);
-          ps1 = ps2 = 0.f;
-          emit(i, 0, cur[0]);
-          emit(i, 1, cur[1]);
-          if (RES) { cur[0] = nxt[0]; cur[1] = nxt[1]; }
+      for (int i = 0; i < 4; ++i) {
+        if (RES && i + 1 < 4) res_row(i + 1, nxt);                       // the next row's residual in flight
+        ps1 = ps2 = 0.f;
+        const u32x4 v0 = make(i, 0, cur[0]);
+        if (GELU) __builtin_amdgcn_sched_barrier(0);                     // one half at a time: erff's temporaries x 16 values spill
+        const u32x4 v1 = make(i, 1, cur[1]);
+        if (RES) { cur[0] = nxt[0]; cur[1] = nxt[1]; }
+        u32x4 da, db;
+        isic_pair_rows(v0, v1, odd, da, db);
+        const int mA = m0 + wm * 64 + i * 16 + (fr & ~1), mB = mA + 1;
+        const size_t col = (size_t)chan + (odd ? 32 : 0);
+        if (mA < a.M) __builtin_nontemporal_store(da, reinterpret_cast<u32x4*>(a.C + (size_t)mA * a.N + col));
+        if (mB < a.M) __builtin_nontemporal_store(db, reinterpret_cast<u32x4*>(a.C + (size_t)mB * a.N + col));
+        if (SOUT) {
+          // the four fg lanes of a row hold its 64 columns of this wave: fixed-order butterfly, lane fg == 0 writes
           float s1 = ps1, s2 = ps2;
           s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
           s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
