@@ -369,6 +369,7 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
       const int m = m0 + wm * 64 + i * 16 + fr;
       const bool valid = m < a.M;
       const unsigned off = (unsigned)(valid ? m : 0) * (unsigned)a.Cout + chan;
+      u32x4 vv[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         u32x4 v;
@@ -394,7 +395,17 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
             s8[t][4 * h + 3] += r3; q8[t][4 * h + 3] += r3 * r3;
           }
         }
-        if (valid) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.out + off + t * 32));
+        vv[t] = v;
+      }
+      // whole 128-byte lines per store instruction (common.h: isic_pair_rows): 8 rows x 128 B instead of 16 rows x 64 B
+      {
+        const bool odd = fr & 1;
+        u32x4 da, db;
+        isic_pair_rows(vv[0], vv[1], odd, da, db);
+        const int mA = m0 + wm * 64 + i * 16 + (fr & ~1), mB = mA + 1;
+        const unsigned col = chan + (odd ? 32u : 0u);
+        if (mA < a.M) __builtin_nontemporal_store(da, reinterpret_cast<u32x4*>(a.out + (unsigned)mA * (unsigned)a.Cout + col));
+        if (mB < a.M) __builtin_nontemporal_store(db, reinterpret_cast<u32x4*>(a.out + (unsigned)mB * (unsigned)a.Cout + col));
       }
     }
     if (STATS == 1) {
