@@ -56,3 +56,29 @@ def intermediate_fusion(p, feats, strategy, drop=None):
     else:
         raise ValueError(strategy)
     return fusion_mlp(p, fused, drop)
+
+
+def attention_fusion_late(p, logits, prefix="attention"):
+    """`model.py:25-40` (AttentionFusion_Late): scores = Linear(M*C,128)->ReLU->Linear(128,M) on the concatenated
+    per-modality logits; softmax over M; weighted sum of the logits."""
+    cat = torch.cat(logits, dim=1)
+    s = F.linear(F.relu(F.linear(cat, p[f"{prefix}.attention_net.0.weight"], p[f"{prefix}.attention_net.0.bias"])),
+                 p[f"{prefix}.attention_net.2.weight"], p[f"{prefix}.attention_net.2.bias"])
+    w = torch.softmax(s, dim=1).unsqueeze(2)
+    return (torch.stack(logits, dim=1) * w).sum(dim=1)
+
+
+def late_fusion(p, feats, modality, strategy):
+    """`model.py:155-164` (one Linear(128,C) head per modality) + the late branches `model.py:216-227`:
+    "concat" is a plain sum of the per-modality logits, "weighted" a softmax(weights)-weighted sum,
+    "attention" AttentionFusion_Late."""
+    logits = [F.linear(f, p[f"modality_heads.{m}.weight"], p[f"modality_heads.{m}.bias"])
+              for m, f in zip(modality, feats)]
+    if strategy == "concat":
+        return torch.stack(logits, dim=1).sum(dim=1)
+    if strategy == "weighted":
+        nw = torch.softmax(p["weights"], dim=0)
+        return torch.stack([w * z for w, z in zip(nw, logits)], dim=0).sum(dim=0)
+    if strategy == "attention":
+        return attention_fusion_late(p, logits)
+    raise ValueError(strategy)

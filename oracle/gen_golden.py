@@ -306,27 +306,43 @@ def main():
                                                                       np.array(bests))
     np.savez_compressed(os.path.join(OUT, "net_utils_loops.npz"), **d)
 
-    # ---------------- radiomics_mlp / AttentionFusion / fusion branches (model.py:6-227)
-    for R in (32, 128):
-        for strat in ("concat", "weighted", "attention"):
-            net = mdl.MultiModalFusionNet(modality=["radiomics", "clinical", "artifacts"],
-                                          fusion_level="intermediate", fusion_strategy=strat, radiomics_dim=R)
-            shapes = formula.shapes_of(net)
-            net.load_state_dict(formula.formula_state_dict(shapes))
-            net.eval()
-            B = 6
-            rad = formula.formula_input(B, R, phase=0.9)
-            age = formula.ftensor((B,), 0.5, 0.3, 0.1)
-            sex = torch.arange(B) % 3
-            loc = torch.arange(B) % 15
-            art = (torch.arange(B * 6).view(B, 6) % 2)
-            logits = net(None, rad, age, sex, loc, art)
-            rf = net.radiomics_mlp(rad)
-            d = {"names": names_blob(shapes), "logits": np_(logits), "rad_feat": np_(rf), "B": np.int64(B), "R": np.int64(R)}
-            if strat == "attention":
-                feats = [rf, formula.formula_input(B, 128, phase=1.7), formula.formula_input(B, 128, phase=2.9)]
-                d["attfusion"] = np_(net.attention(feats))
-            np.savez_compressed(os.path.join(OUT, f"fusion_{strat}_R{R}.npz"), **d)
+    # ---------------- radiomics_mlp / AttentionFusion(_Late) / fusion branches (model.py:6-40, 206-227)
+    # forward logits AND the gradient of CE(logits, target) w.r.t. every parameter the forward touches, for both
+    # fusion levels ("late": per-modality heads model.py:155-164, sum / softmax-weighted / AttentionFusion_Late :216-227)
+    for level in ("intermediate", "late"):
+        for R in (32, 128):
+            for strat in ("concat", "weighted", "attention"):
+                net = mdl.MultiModalFusionNet(modality=["radiomics", "clinical", "artifacts"],
+                                              fusion_level=level, fusion_strategy=strat, radiomics_dim=R)
+                shapes = formula.shapes_of(net)
+                net.load_state_dict(formula.formula_state_dict(shapes))
+                net.eval()
+                B = 6
+                rad = formula.formula_input(B, R, phase=0.9)
+                age = formula.ftensor((B,), 0.5, 0.3, 0.1)
+                sex = torch.arange(B) % 3
+                loc = torch.arange(B) % 15
+                art = (torch.arange(B * 6).view(B, 6) % 2)
+                target = (torch.arange(B) * 3 + 1) % 7
+                net.zero_grad()
+                logits = net(None, rad, age, sex, loc, art)
+                loss = nn.CrossEntropyLoss()(logits, target)
+                loss.backward()
+                rf = net.radiomics_mlp(rad)
+                d = {"names": names_blob(shapes), "logits": np_(logits), "rad_feat": np_(rf), "B": np.int64(B),
+                     "R": np.int64(R), "target": np_(target), "loss": np_(loss)}
+                for k, prm in net.named_parameters():
+                    if prm.grad is None:
+                        continue                      # image branch: not part of this forward
+                    put_grads(d, "grad.", {k: prm.grad}, full=prm.numel() <= 4096)
+                if strat == "attention" and level == "intermediate":
+                    feats = [rf, formula.formula_input(B, 128, phase=1.7), formula.formula_input(B, 128, phase=2.9)]
+                    d["attfusion"] = np_(net.attention(feats))
+                if strat == "attention" and level == "late":
+                    lg = [formula.formula_input(B, 7, phase=1.7 + 1.2 * i) for i in range(3)]
+                    d["attfusion_late"] = np_(net.attention(lg))
+                name = f"fusion_{strat}_R{R}.npz" if level == "intermediate" else f"fusion_late_{strat}_R{R}.npz"
+                np.savez_compressed(os.path.join(OUT, name), **d)
 
     # ---------------- metrics (sklearn; 05:290,299)
     from sklearn.metrics import balanced_accuracy_score, roc_auc_score

@@ -11,14 +11,18 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.mark.parametrize("level", ["intermediate", "late"])
 @pytest.mark.parametrize("R", [32, 128])
 @pytest.mark.parametrize("strat", ["concat", "weighted", "attention"])
-def test_fusion_net_golden(R, strat):
-    """radiomics_mlp / clinical / artifact MLPs + fusion head vs golden vectors produced by the
-    reference's own MultiModalFusionNet (model.py:166-227).  fp32 tolerance 5e-5."""
+def test_fusion_net_golden(R, strat, level):
+    """radiomics_mlp / clinical / artifact MLPs + the fusion branches of BOTH levels (intermediate: `model.py:206-216`;
+    late: per-modality heads `:155-164`, sum / softmax-weighted / AttentionFusion_Late `:25-40`, `:216-227`) vs golden
+    vectors produced by the reference's own MultiModalFusionNet: logits (fp32 tolerance 5e-5), the CE loss, and the
+    gradient of every parameter the reference's backward reached (3e-4 of the tensor's scale)."""
+    from helpers import check_grad
     from model import MultiModalFusionNet
-    g = load_golden(f"fusion_{strat}_R{R}.npz")
-    net = MultiModalFusionNet(modality=["radiomics", "clinical", "artifacts"], fusion_level="intermediate",
+    g = load_golden(f"fusion_{strat}_R{R}.npz" if level == "intermediate" else f"fusion_late_{strat}_R{R}.npz")
+    net = MultiModalFusionNet(modality=["radiomics", "clinical", "artifacts"], fusion_level=level,
                               fusion_strategy=strat, radiomics_dim=R)
     p = formula_params(g)
     missing = net.load_state_dict({k: v for k, v in p.items() if not k.startswith(("image_model", "image_proj"))},
@@ -32,6 +36,22 @@ def test_fusion_net_golden(R, strat):
     art = (torch.arange(B * 6).view(B, 6) % 2).to(DEV)
     logits = net(None, rad, age, sex, loc, art)
     assert_close(logits, g["logits"], rtol=5e-5, atol=5e-6, what="logits")
+    loss = torch.nn.CrossEntropyLoss()(logits, torch.from_numpy(g["target"]).to(DEV))   # as net_utils.train does
+    assert abs(float(loss.detach()) - float(g["loss"])) < 5e-5
+    loss.backward()
+    keys = sorted({k[5:].split("#")[0] for k in g.files if k.startswith("grad.")})
+    params = dict(net.named_parameters())
+    assert keys and all(k in params for k in keys)
+    for k in keys:
+        gr = params[k].grad
+        assert gr is not None, k
+        check_grad(g, k, gr, rtol=3e-4, atol=1e-7)
+    for k, prm in params.items():
+        if k not in keys:
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, k
+    if strat == "attention" and level == "late":
+        lg = [formula.formula_input(B, 7, phase=1.7 + 1.2 * i).to(DEV) for i in range(3)]
+        assert_close(net.attention(lg), g["attfusion_late"], rtol=5e-5, atol=5e-6, what="attfusion_late")
 
 
 def test_milnet_forward_and_step_vs_oracle():

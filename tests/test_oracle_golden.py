@@ -97,11 +97,14 @@ def test_graphmil_mlp(tag):
         check_grad(g, k, grads[k])
 
 
+@pytest.mark.parametrize("level", ["intermediate", "late"])
 @pytest.mark.parametrize("R", [32, 128])
 @pytest.mark.parametrize("strat", ["concat", "weighted", "attention"])
-def test_fusion(R, strat):
-    g = load_golden(f"fusion_{strat}_R{R}.npz")
-    p = formula_params(g)
+def test_fusion(R, strat, level):
+    """oracle/fusion.py vs the reference's own MultiModalFusionNet (model.py:166-227), both fusion levels: logits, the
+    CE loss and the gradient of every parameter the forward touches."""
+    g = load_golden(f"fusion_{strat}_R{R}.npz" if level == "intermediate" else f"fusion_late_{strat}_R{R}.npz")
+    p = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in formula_params(g).items()}
     B = int(g["B"])
     rad = formula.formula_input(B, R, phase=0.9)
     rf = fusion.mlp_ln_relu(p, "radiomics_mlp", rad)
@@ -114,11 +117,27 @@ def test_fusion(R, strat):
     cf = fusion.mlp_ln_relu(p, "clinical_mlp", clin)
     af = fusion.mlp_ln_relu(p, "artifact_mlp",
                             torch.cat([p[f"artifact_embeddings.{i}.weight"][art[:, i]] for i in range(6)], dim=1))
-    logits = fusion.intermediate_fusion(p, [rf, cf, af], strat)
+    if level == "intermediate":
+        logits = fusion.intermediate_fusion(p, [rf, cf, af], strat)
+    else:
+        logits = fusion.late_fusion(p, [rf, cf, af], ["radiomics", "clinical", "artifacts"], strat)
     assert_close(logits, g["logits"], rtol=5e-5, atol=5e-6, what="logits")
-    if strat == "attention":
+    loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(g["target"]))
+    assert abs(float(loss) - float(g["loss"])) < 2e-5
+    loss.backward()
+    keys = sorted({k[5:].split("#")[0] for k in g.files if k.startswith("grad.")})
+    assert keys and all(k in p for k in keys)
+    for k in keys:
+        check_grad(g, k, p[k].grad if p[k].grad is not None else torch.zeros_like(p[k]))
+    for k, v in p.items():          # what the reference's backward did not reach, the oracle's must not either
+        if k not in keys and v.dtype.is_floating_point:
+            assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
+    if strat == "attention" and level == "intermediate":
         feats = [rf, formula.formula_input(B, 128, phase=1.7), formula.formula_input(B, 128, phase=2.9)]
         assert_close(fusion.attention_fusion(p, feats)[0], g["attfusion"], rtol=2e-5, atol=2e-6)
+    if strat == "attention" and level == "late":
+        lg = [formula.formula_input(B, 7, phase=1.7 + 1.2 * i) for i in range(3)]
+        assert_close(fusion.attention_fusion_late(p, lg), g["attfusion_late"], rtol=2e-5, atol=2e-6)
 
 
 def test_metrics():
