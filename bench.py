@@ -169,7 +169,7 @@ def kernel_source_hash(prefixes=None):
 TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 TRAFFIC_SOURCES = {
     "mil": ("conv_igemm", "conv_halo", "conv_pgemm", "conv_c64"),      # kernels behind isic_conv2d_igemm_bf16
-    "gnn": ("graph",),                                                  # isic_spmm_csr_f32
+    "gnn": ("graph.",),                                                 # isic_spmm_csr_f32
     "vit": ("gemm_f16",),                                               # isic_gemm_f16
 }
 

@@ -118,6 +118,9 @@ int isic_multi_copy_f32(int nseg, float* const* dst, const float* const* src, co
  *                               `counter`: one zero uint32 (left zero); dropout as isic_relu_dropout_fwd_clk_f32 on [B, D];
  *   isic_graph_head_param_grads: dW1[D, H], db1[D], dW2[C, D], db2[C] (+= when accumulate) = grad_scale[0] (device scalar,
  *                               NULL = 1) * the contributions added in block order.  C <= 15. */
+/* 1 when the fused head handles the shape (C < 16 and W1 twice + the row tiles fit 160 KB of LDS: H * D <= ~19 k, e.g.
+ * H = D = 128), else 0: the caller then runs the operator chain (isic_gemm_f32 / isic_softmax_rows / isic_cross_entropy). */
+int isic_graph_head_supported(int H, int D, int C);
 size_t isic_graph_head_workspace_bytes(int B, int H, int D, int C);
 int isic_graph_head_fwd_bwd(const float* z, const float* W1, const float* b1, const float* W2, const float* b2,
                             const int64_t* labels, int B, int H, int D, int C, uint32_t drop_threshold, float drop_scale,
@@ -244,8 +247,9 @@ int isic_softmax_rows_bwd(const float* probs, const float* d_probs, float* d_log
 int isic_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float step_size, float beta1, float beta2,
                    float eps, float decay_factor, float l2, float bias_correction2_sqrt, float grad_scale,
                    uint16_t* p_bf16, void* stream);
-/* ... with t = clock[1] + 1 read on the device: step_size = lr / (1 - beta1^t), bias_correction2_sqrt = sqrt(1 - beta2^t) */
-int isic_adam_step_clk(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+/* ... with t = clock[1] + 1 read on the device: step_size = lr / (1 - beta1^t) (lr in double, one rounding to fp32 as on the
+ * host), bias_correction2_sqrt = sqrt(1 - beta2^t) */
+int isic_adam_step_clk(float* p, const float* g, float* m, float* v, int64_t n, double lr, float beta1, float beta2,
                        float eps, float decay_factor, float l2, float grad_scale, uint16_t* p_bf16, const uint64_t* clock,
                        void* stream);
 

@@ -106,7 +106,10 @@ __global__ __launch_bounds__(HT) void graph_head_kernel(HeadArgs a) {
   // ---- softmax, loss, d logits (one thread per row; the arithmetic of softmax_rows_fwd / cross_entropy (mode 1) /
   //      softmax_rows_bwd of rowwise.hip, d loss = 1)
   if (tid < nr) {
-    const int r = tid, y = (int)a.labels[r0 + r];
+    const int r = tid;
+    const long long yl = a.labels[r0 + r];
+    const bool bad_label = yl < 0 || yl >= C;             // a label outside [0, C): the row's loss (and the mean) is NaN
+    const int y = bad_label ? 0 : (int)yl;
     float p[MAXC], dp[MAXC];
     float mx = -INFINITY;
     for (int c = 0; c < C; ++c) mx = fmaxf(mx, lg[r * MAXC + c]);
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(HT) void graph_head_kernel(HeadArgs a) {
     float qs = 0.f;
     for (int c = 0; c < C; ++c) qs += expf(logf(p[c] + 1e-9f) - qm);
     const float lse = qm + logf(qs);
-    const float lossr = lse - logf(p[y] + 1e-9f);
+    const float lossr = bad_label ? NAN : lse - logf(p[y] + 1e-9f);
     a.loss_ps[r0 + r] = lossr;
     lg[r * MAXC + MAXC - 1] = lossr;                       // (C < MAXC: the slot is free) for the block's loss sum
     const float gs = 1.f / (float)a.B;
@@ -220,6 +223,11 @@ size_t head_lds_bytes(int H, int D, int C) {
 
 extern "C" {
 
+int isic_graph_head_supported(int H, int D, int C) {
+  if (H <= 0 || D <= 0 || C <= 0 || C >= MAXC) return 0;
+  return head_lds_bytes(H, D, C) <= 160 * 1024 - 256 ? 1 : 0;   // (the kernel has a few static bytes of its own)
+}
+
 size_t isic_graph_head_workspace_bytes(int B, int H, int D, int C) {
   if (B <= 0 || H <= 0 || D <= 0 || C <= 0) return 0;
   return (size_t)ceil_div(B, RH) * ((size_t)D * H + D + (size_t)C * D + C + 1) * sizeof(float);   // + the block's loss sum
@@ -232,9 +240,8 @@ int isic_graph_head_fwd_bwd(const float* z, const float* W1, const float* b1, co
                             void* stream) {
   ISIC_CHECK_ARG(B > 0 && H > 0 && D > 0 && C > 0);
   ISIC_CHECK_ARG(z && W1 && b1 && W2 && b2 && labels && probs && loss_per_sample && loss_mean && dz && workspace && counter);
-  if (C >= MAXC) return ISIC_ERR_UNSUPPORTED;
+  if (!isic_graph_head_supported(H, D, C)) return ISIC_ERR_UNSUPPORTED;
   const size_t lds = head_lds_bytes(H, D, C);
-  if (lds > 160 * 1024 - 256) return ISIC_ERR_UNSUPPORTED;   // (the kernel has a few static bytes of its own)
   if (workspace_bytes < isic_graph_head_workspace_bytes(B, H, D, C) || (reinterpret_cast<uintptr_t>(workspace) & 15))
     return ISIC_ERR_WORKSPACE;
   static IsicPerDeviceOnce once;

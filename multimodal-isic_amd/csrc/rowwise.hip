@@ -344,12 +344,12 @@ __global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict_
                                  float* __restrict__ v, int64_t n, float step_size, float beta1, float beta2,
                                  float eps, float decay_factor, float l2, float bc2_sqrt, float grad_scale,
                                  unsigned short* __restrict__ p_bf16, const unsigned long long* __restrict__ clock,
-                                 float lr) {
+                                 double lr) {
   if (clock) {
     // device step clock (captured graphs): t = clock[1] + 1; step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t),
     // formed in fp64 as the host does (optim.py)
     const double t = (double)(clock[1] + 1ULL);
-    step_size = (float)((double)lr / (1.0 - pow((double)beta1, t)));
+    step_size = (float)(lr / (1.0 - pow((double)beta1, t)));     // one rounding, as the host's lr / bc1
     bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, t));
   }
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -541,11 +541,11 @@ int isic_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(adam_step_kernel, dim3((int)grid), dim3(256), 0, as_stream(stream), p, g, m, v, n, step_size,
                      beta1, beta2, eps, decay_factor, l2, bias_correction2_sqrt, grad_scale, p_bf16,
-                     (const unsigned long long*)nullptr, 0.f);
+                     (const unsigned long long*)nullptr, 0.0);
   return isic_launch_status();
 }
 
-int isic_adam_step_clk(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+int isic_adam_step_clk(float* p, const float* g, float* m, float* v, int64_t n, double lr, float beta1, float beta2,
                        float eps, float decay_factor, float l2, float grad_scale, uint16_t* p_bf16, const uint64_t* clock,
                        void* stream) {
   ISIC_CHECK_ARG(n >= 0 && clock);

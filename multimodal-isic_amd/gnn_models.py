@@ -307,7 +307,8 @@ class GraphMIL(nn.Module):
         W2, b2, w3, b3 = ops.head_params(self.attention_layers)      # the heads' parameters as one [heads*A, H] operand
         z, att = ops.attn_pool(h, W2, b2, w3, b3, offs.device, offs.max_bag, heads=self.att_heads)
         c = self.classifier
-        if labels is not None and self.classifier_light and tr and not single:
+        if (labels is not None and self.classifier_light and tr and not single
+                and ops.graph_head_supported(z.shape[1], c[0].weight.shape[0], c[3].weight.shape[0])):
             probs, loss = ops.graph_head_loss(z, c[0].weight, c[0].bias, c[3].weight, c[3].bias, labels,
                                               clk.spec(c[2].p, 64, tr))
             clk.step += 1

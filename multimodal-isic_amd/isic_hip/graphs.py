@@ -9,7 +9,9 @@ kernels for ~1.3 ms of GPU work: the host needs longer to enqueue it than the GP
   by the ``_clk`` C-ABI entries, advanced by the last kernel of the step) instead of host scalars frozen at capture;
 * the step's inputs (graph indices, labels) live in static tensors the caller overwrites before ``replay()``.
 
-With the clock at step s the captured step is, bit for bit, the eager step s (tests/test_train_gpu.py).
+With the clock at step s the captured step is the eager step s to the tolerance tests/test_train_gpu.py states (loss 1e-6,
+parameters 2e-5: the clock form of AdamW forms lr / (1 - beta1^t) on the device in double precision from a double lr; the
+eager form rounds the host's double quotient once -- the step sizes agree to 1 ulp of fp32).
 """
 from __future__ import annotations
 
@@ -50,21 +52,38 @@ class StepClock:
                 if clk is not None:
                     clk.device_clock = None
         if optimizer is not None:
+            if hasattr(optimizer, "sync_clock"):
+                optimizer.sync_clock()               # the host step count continues from the steps the clock counted
             optimizer.device_clock = None
 
 
 class CapturedStep:
     """``body()`` -- one whole train step reading only static tensors -- warmed up on a side stream and captured once;
-    ``replay()`` runs it again.  ``body`` must end with ``clock.advance()`` when it uses a ``StepClock``."""
+    ``replay()`` runs it again.  ``body`` must end with ``clock.advance()`` when it uses a ``StepClock``.
 
-    def __init__(self, body, warmup=3):
+    The warm-up runs ``body`` ``warmup`` times for real (allocator growth, one-time kernel attributes, autograd shapes):
+    those are optimizer updates and clock advances on whatever the static inputs hold.  Pass ``optimizer`` and ``clock``
+    (and ``buffers``: any other tensors the step mutates, e.g. BatchNorm running statistics) and the flat parameters, both
+    Adam moments, the clock and the buffers are snapshotted before the warm-up and restored after it, so that the first
+    ``replay()`` is step ``clock[1] + 1`` of the run; without them the warm-up CONSUMES ``warmup`` steps."""
+
+    def __init__(self, body, warmup=3, optimizer=None, clock=None, buffers=()):
         self.body = body
+        saved = []
+        if optimizer is not None:
+            saved += [optimizer.flat.data, optimizer.exp_avg, optimizer.exp_avg_sq]
+        if clock is not None:
+            saved.append(clock.tensor)
+        saved += list(buffers)
+        snap = [t.clone() for t in saved]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):          # allocator growth, one-time kernel attribute setup, autograd graph shapes
                 body()
         torch.cuda.current_stream().wait_stream(side)
+        for t, c in zip(saved, snap):
+            t.copy_(c)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):

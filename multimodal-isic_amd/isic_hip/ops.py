@@ -567,7 +567,8 @@ class GraphHeadLossFn(torch.autograd.Function):
         D, C = W1.shape[0], W2.shape[0]
         drop = drop or NO_DROP
         dev = z2.device
-        key = (dev.type, dev.index)
+        # one ticket counter per (device, stream): two head launches in flight on different streams never share one
+        key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
         cnt = _HEAD_COUNTER.get(key)
         if cnt is None:
             cnt = _HEAD_COUNTER[key] = torch.zeros(64, device=dev, dtype=torch.int32)
@@ -603,8 +604,13 @@ class GraphHeadLossFn(torch.autograd.Function):
         return (gz,) + ((None,) * 4 if fused else tuple(outs)) + (None, None)
 
 
+def graph_head_supported(H, D, C):
+    """Whether ``graph_head_loss`` handles Linear(H, D) -> Linear(D, C) (LDS bound, C < 16); else use the operator chain."""
+    return bool(call("isic_graph_head_supported", int(H), int(D), int(C)))
+
+
 def graph_head_loss(z, W1, b1, W2, b2, labels, drop=None):
-    """-> (probs[B, C], mean loss)."""
+    """-> (probs[B, C], mean loss).  A label outside [0, C) makes the loss NaN."""
     probs, loss, _ = GraphHeadLossFn.apply(z, W1, b1, W2, b2, labels, drop)
     return probs, loss
 

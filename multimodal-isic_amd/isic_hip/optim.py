@@ -80,12 +80,23 @@ class _FlatAdamBase:
              lr / bc1, b1, b2, float(g["eps"]), (1.0 - lr * wd) if self.decoupled else 1.0,
              0.0 if self.decoupled else wd, bc2_sqrt, float(grad_scale), None)
 
+    def sync_clock(self):
+        """While a device step clock is attached the step count lives in HBM (clock[1]); bring the host copy up to date
+        (called by ``state_dict`` and by ``graphs.StepClock.detach``: a checkpoint or a switch back to eager steps must
+        continue Adam's bias correction from the steps actually taken)."""
+        if self.device_clock is not None:
+            self.t = int(self.device_clock[1].item())
+        return self.t
+
     def state_dict(self):
+        self.sync_clock()
         return {"t": self.t, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
                 "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
 
     def load_state_dict(self, sd):
         self.t = int(sd["t"])
+        if self.device_clock is not None:
+            self.device_clock[1] = self.t
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.param_groups[0].update(sd["param_groups"][0])

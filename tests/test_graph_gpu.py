@@ -408,6 +408,68 @@ def test_graph_head_loss_fused_equals_the_operator_chain(p_drop, B):
     # through the model: GraphMIL(labels=...) in training mode == forward + cross_entropy_from_probs
 
 
+def test_graph_head_supported_bound_and_bad_label():
+    """isic_graph_head_supported mirrors the kernel's own LDS / class bound (the entry returns ERR_UNSUPPORTED exactly where
+    the query says 0), and a label outside [0, C) turns the fused loss into NaN instead of reading past the row's probabilities."""
+    from isic_hip import ops
+    from isic_hip.lib import IsicHipError
+    assert ops.graph_head_supported(128, 128, 7) and ops.graph_head_supported(32, 24, 7)
+    assert not ops.graph_head_supported(256, 128, 7) and not ops.graph_head_supported(128, 128, 16)
+    gen = torch.Generator().manual_seed(2)
+    mk = lambda *s: torch.randn(*s, generator=gen).to(DEV)
+    z, W1, b1, W2, b2 = mk(9, 256), mk(128, 256), mk(128), mk(7, 128), mk(7)
+    y = torch.arange(9).to(DEV) % 7
+    with pytest.raises(IsicHipError):
+        ops.graph_head_loss(z, W1, b1, W2, b2, y)
+    z, W1 = mk(9, 128), mk(128, 128)
+    _, loss = ops.graph_head_loss(z, W1, b1, W2, b2, y)
+    assert torch.isfinite(loss)
+    y[4] = 7
+    _, loss = ops.graph_head_loss(z, W1, b1, W2, b2, y)
+    assert torch.isnan(loss)
+
+
+@pytest.mark.parametrize("hidden", [128, 256])
+def test_graphmil_train_step_with_labels_fused_head_and_fallback(hidden):
+    """GraphMIL(labels=...) in training mode at the reference CLI's `--hidden-dim 256` (05_train_gnns.py:407; the fused head's
+    LDS bound stops at ~136: the operator chain must take over) and at 128 (fused head): probabilities, loss and every parameter
+    gradient equal the plain forward + cross_entropy_from_probs path with the same dropout words (fp32 summation-order tolerance)."""
+    from gnn_models import GraphMIL
+    from isic_hip import ops, train as T
+    gen = torch.Generator().manual_seed(17)
+    G, n, D, k = 12, 40, 48, 4
+    recs = []
+    for i in range(G):
+        src = torch.arange(n).repeat_interleave(k)
+        dst = (src + 1 + torch.randint(0, n - 1, (n * k,), generator=gen)) % n
+        recs.append({"x": torch.randn(n, D, generator=gen), "edge_index": torch.stack([src, dst]), "y": i % 7})
+    store = T.GraphStore(recs, torch.device(DEV), True, mode="gcn")
+    torch.manual_seed(6)
+    model = GraphMIL(input_dim=D, gnn_type="gcn", gnn_hidden=hidden, gnn_layers=2, gnn_dropout=0.5, att_dim=32, att_heads=4,
+                     pool_dropout=0.2, classifier_dim=128, classifier_light=True, num_classes=7).to(DEV)
+    model.train()
+    assert ops.graph_head_supported(hidden, 128, 7) == (hidden == 128)
+    idx = torch.arange(G).to(DEV)
+    y = store.y_dev[idx]
+    params = list(model.parameters())
+    x, offs, g = store.batch(idx)
+
+    def run(with_labels):
+        model.set_dropout_state(seed=4, step=0)
+        if with_labels:
+            probs, _att, loss = model(x, offsets=offs, graph=g, labels=y)
+        else:
+            probs, _att = model(x, offsets=offs, graph=g)
+            loss = ops.cross_entropy_from_probs(probs, y)
+        return probs.detach().clone(), loss.detach().clone(), torch.autograd.grad(loss, params)
+    pa, la, ga = run(False)
+    pb, lb, gb = run(True)
+    assert_close(pb, pa, rtol=2e-5, atol=1e-6, what="probs")
+    assert_close(lb, la, rtol=2e-6, atol=1e-6, what="loss")
+    for (name, _), u, v in zip(model.named_parameters(), gb, ga):
+        assert_close(u, v, rtol=3e-4, atol=3e-7, what=name)
+
+
 def test_linear_rows_reads_through_the_index_like_gather_then_linear():
     """ops.linear_rows (isic_gemm_f32_rows_ws: the persistent GEMM reads its row operand through an int32 index, forward as A rows,
     weight gradient as the k rows of B) == gather + ops.linear bit for bit (same kernel, same summation order), on a batch of

@@ -401,7 +401,7 @@ def test_captured_gnn_step_equals_eager_steps():
         losses.append(float(loss.detach()))
     ref = {k: v.detach().clone() for k, v in m.state_dict().items()}
 
-    # ---- captured: device clock; warm-up and capture disturb parameters and clock, so both are reset before the replays
+    # ---- captured: device clock; CapturedStep snapshots parameters, Adam moments and the clock around its warm-up steps
     m2, opt2, store2 = make()
     p0 = opt2.flat.data.clone()
     idx = torch.zeros(Gs, device=dev, dtype=torch.int64)
@@ -417,11 +417,9 @@ def test_captured_gnn_step_equals_eager_steps():
         clock.advance()
         return loss
     idx.copy_(batches[0])
-    cap = G.CapturedStep(body)
-    opt2.flat.data.copy_(p0)
-    opt2.exp_avg.zero_()
-    opt2.exp_avg_sq.zero_()
-    clock.tensor.zero_()
+    cap = G.CapturedStep(body, optimizer=opt2, clock=clock)
+    assert torch.equal(opt2.flat.data, p0) and clock.read() == (0, 0)            # the warm-up left no trace
+    assert float(opt2.exp_avg.abs().max()) == 0.0 and float(opt2.exp_avg_sq.abs().max()) == 0.0
     got = []
     for s in range(steps):
         idx.copy_(batches[s])
@@ -434,7 +432,10 @@ def test_captured_gnn_step_equals_eager_steps():
         if k.startswith("attention_layers.") and k.endswith(".2.bias"):
             continue      # analytically zero gradient (softmax shift invariance): Adam amplifies its rounding noise to +-lr
         assert float((v - ref[k]).abs().max()) <= 2e-5 * float(ref[k].abs().max()) + 1e-8, k
+    # the optimizer's host step count follows the device clock: a checkpoint / a switch back to eager continues from `steps`
+    assert opt2.t == 0 and opt2.state_dict()["t"] == steps
     G.StepClock.detach(m2, opt2)
+    assert opt2.t == steps and opt2.device_clock is None
 
 
 def test_fused_grad_accumulation_equals_autograd_accumulation():
