@@ -563,8 +563,9 @@ def run_gnn(args, world, rank, dev):
 def cpu_baseline_gnn(model, records, budget_s):
     """oracle/ per-graph 05 loop (`05_train_gnns.py:336-346`: one graph per optimizer step, fp32, torch CPU, AdamW)."""
     from oracle import gnn as ognn
+    # dropout as in the GPU step beside it (gnn_dropout 0.5, classifier dropout 0.2; the oracle draws the same Philox words)
     cfg = dict(gnn_type="gcn", gnn_hidden=model.gnn_layers[0].lin.weight.shape[0], gnn_layers=len(model.gnn_layers),
-               gnn_dropout=0.0, att_dim=128, classifier_dim=128, pool_dropout=0.0)
+               gnn_dropout=0.5, att_dim=128, classifier_dim=128, pool_dropout=0.2)
     p0 = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     recs = [{"x": r["x"].cpu(), "edge_index": r["edge_index"].cpu(), "y": r["y"]} for r in records[:64]]
     default_threads, threads = torch.get_num_threads(), host_threads()
@@ -577,7 +578,7 @@ def cpu_baseline_gnn(model, records, budget_s):
         def one(i):
             r = recs[i % len(recs)]
             opt.zero_grad()
-            out = ognn.graphmil_forward(q, cfg, r["x"], r["edge_index"])
+            out = ognn.graphmil_forward(q, cfg, r["x"], r["edge_index"], drop={"seed": 42, "stream_base": i * 1024})
             ognn.graph_loss(out["probs"], r["y"]).backward()
             opt.step()
         for i in range(warm):
@@ -599,11 +600,255 @@ def cpu_baseline_gnn(model, records, budget_s):
     # CPU figure is the faster setting and both are listed
     best, cores, done = (v_one, 1, d_one) if v_one >= v_all else (v_all, threads, d_all)
     return {"value": best, "unit": "graphs/s", "cores": cores, "kind": "port",
-            "sample": f"{done} per-graph train steps (one 196-node graph per optimizer step, fp32, torch CPU, {cores} "
-                      f"thread(s)) after 30 warm-up steps",
+            "sample": f"{done} per-graph train steps (one 196-node graph per optimizer step, dropout 0.5 / 0.2 as the GPU step, "
+                      f"fp32, torch CPU, {cores} thread(s)) after 30 warm-up steps",
             "all_threads": {"value": v_all, "cores": threads, "sample": f"{d_all} steps after 30 warm-up steps"},
             "one_thread": {"value": v_one, "cores": 1, "sample": f"{d_one} steps after 30 warm-up steps"},
             "host_cpus": os.cpu_count()}
+
+
+# ----------------------------------------------------------------------------------------------- the reference's own hot loop
+WORKLOAD_TEACHER = ("MIL teacher train step on resident [196, 768] fp32 latents (the reference's own hot loop, "
+                    "01_train_mil_teacher.py:235-246 / utils_g_mil.py:66-105), B bags per optimizer step")
+
+
+def run_teacher(args, world, rank, dev, H=None, A=None, with_cpu=True):
+    """One step = forward + backward + AdamW of AttentionMIL_teacher over ``--teacher-bags-per-step`` bags of 196 x 768 fp32
+    latents resident in HBM (mean of the per-bag losses of 01:244; SURVEY.md 7 "batch-vs-per-bag"), replayed as a hipGraph with
+    the device step clock (dropout words and Adam's t follow the step).  Roofline ("MIL head + attention pool --
+    HBM bound"): the head's kernels (fp32 GEMMs + attention pool, forward and backward) against the algorithmic bytes of a
+    train step: x read by the forward projection and again by its weight gradient + the five outputs written."""
+    from isic_hip import ddp, graphs as G, ops, optim
+    from isic_hip.bags import BagOffsets
+    from utils_g_mil import AttentionMIL_teacher
+    N, D, C = 196, 768, 7
+    H, A = H or args.teacher_hidden, A or args.teacher_att
+    B = args.teacher_bags_per_step
+    torch.manual_seed(42)
+    model = AttentionMIL_teacher(D, H, A, 0.5, C).to(dev)
+    model.train()
+    model.set_dropout_state(seed=42, step=0)
+    opt = optim.AdamW(model.parameters(), lr=2.2e-4, weight_decay=8.6e-4)        # the reference's tuned values (01:217-224)
+    ddp.broadcast_parameters(opt.flat.data)
+    sync = ddp.GradSync(opt.flat.grad, world_size=world)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    n_sets = 4
+    ys = [(torch.arange(B, device=dev) + s + rank) % C for s in range(n_sets)]
+    xs = [(torch.randn(B, N, D, device=dev, generator=gen) + 0.25 * ys[s].view(B, 1, 1).float()).reshape(B * N, D)
+          for s in range(n_sets)]
+    offs = BagOffsets.uniform(B, N, dev)
+    timer = KernelTimer.get()
+    use_graph = world == 1 and not args.no_graph
+    clock = G.StepClock(dev).attach(model, opt) if use_graph else None
+
+    def make_body(s):
+        def body():
+            opt.zero_grad()
+            sync.reset()
+            with ops.fused_grad_accumulation():
+                out = model(xs[s], offs)
+                loss = ops.cross_entropy(out["bag_logits"], ys[s])
+                ops.backward(loss)
+            sync.finish()
+            opt.step(grad_scale=1.0 / world)
+            if clock is not None:
+                clock.advance()
+            return loss
+        return body
+    bodies = [make_body(s) for s in range(n_sets)]
+
+    def eager_step(i):
+        return bodies[i % n_sets]()
+    for i in range(2):
+        eager_step(i)
+    captured = [G.CapturedStep(b, optimizer=opt, clock=clock) for b in bodies] if use_graph else None
+
+    def step(i):
+        return captured[i % n_sets].replay() if captured is not None else eager_step(i)
+    for i in range(args.warmup):
+        step(i)
+    elapsed, host_s, loss = timed_region(step, args, world, dev, timer, [], 0)
+    timer.stop()
+    final_loss = float(loss.detach())
+    # per-entry durations: the same steps launched eagerly right after the timed region, events around every launch
+    n_inst = min(args.steps, 20)
+    torch.cuda.synchronize()
+    timer.start(None)
+    for i in range(n_inst):
+        eager_step(i)
+    torch.cuda.synchronize()
+    rec = timer.stop()
+    if rank != 0:
+        return None
+    split = split_by_class(rec, n_inst)
+    head = [(n_, a, m) for n_, a, m in rec if n_.startswith(("isic_gemm_f32", "isic_attn_pool", "isic_colsum"))]
+    head_ms = sum(m for _n, _a, m in head) / n_inst
+    gemm = [(a, m) for n_, a, m in rec if n_ in ("isic_gemm_f32_ws", "isic_gemm_f32")]
+    gemm_ms = sum(m for _a, m in gemm)
+    gemm_fl = sum(2.0 * a[2] * a[3] * a[4] for a, _m in gemm)                  # (transA, transB, M, N, K, ...)
+    # algorithmic bytes of one TRAIN step per bag (SURVEY.md 8d): forward reads x [N, D] fp32 and writes patch_logits,
+    # patch_probs [N, C], attention [N], bag_logits, bag_probs [C]; backward reads x once more (dW1 = dh^T x; x needs no gradient)
+    fwd_b = N * D * 4 + (2 * N * C + N + 2 * C) * 4
+    bwd_b = N * D * 4
+    step_bytes = B * (fwd_b + bwd_b)
+    gbs = step_bytes / (head_ms * 1e-3) / 1e9 if head_ms > 0 else 0.0
+    line = base_line("bags/sec (MIL teacher train step) @ 196x768 fp32 latents", "bags/s", world * B * args.steps / elapsed,
+                     world, args, elapsed, "f32")
+    line["config"] = {"workload": WORKLOAD_TEACHER, "bags_per_step_per_gpu": B, "patches_per_bag": N, "feat": D, "hidden": H,
+                      "att_dim": A, "params": sum(p.numel() for p in model.parameters()), "parallelism": f"dp{world}",
+                      "host_enqueue_ms_per_step": host_s * 1e3 / args.steps, "final_loss": final_loss,
+                      "step_launch": "hipGraph replay (device step clock)" if captured is not None else "eager"}
+    line["roofline"] = {
+        "bound": "hbm", "kernel": "the head's C-ABI entries of one train step: isic_gemm_f32(_ws) (x W1^T + ReLU + dropout, "
+                                  "h W2^T, their data / weight gradients), isic_attn_pool_fwd / _bwd, column sums",
+        "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+        "launches": len(head) // n_inst, "avg_launch_ms": head_ms / max(len(head) // n_inst, 1),
+        "algorithmic_bytes_per_bag": fwd_b + bwd_b, "algorithmic_bytes_per_step": step_bytes,
+        "kernel_ms_per_step": head_ms, "share_of_step_time": head_ms * 1e-3 * args.steps / elapsed,
+        "mfma": {"achieved": gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0, "peak": MFMA_F32_PEAK_TFLOPS,
+                 "unit": "TFLOP/s", "frac": (gemm_fl / (gemm_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS) if gemm_ms > 0 else 0.0,
+                 "note": "the fp32 GEMMs alone (v_mfma_f32_16x16x4_f32): at 64-150 FLOP per algorithmic byte they sit above the "
+                         "fp32 machine balance of 157.3 TF / 8 TB/s = 20, so the matrix core bounds them, not HBM"},
+        "measured": "HIP events around every launch of an eager pass of the same steps right after the timed region "
+                    "(the timed region replays hipGraphs of the step)" if captured is not None else "HIP events, eager steps",
+    }
+    line["kernel_time"] = split
+    if world == 1 and with_cpu and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_teacher(model, N, D, C, args.cpu_budget_s)
+    if clock is not None:
+        G.StepClock.detach(model, opt)
+    return line
+
+
+def cpu_baseline_teacher(model, N, D, C, budget_s):
+    """oracle/mil.py per-bag loop (`01_train_mil_teacher.py:235-246`: one bag per optimizer step, fp32, torch CPU, AdamW),
+    >= 200 steps after 30 warm-up steps, at one thread and at the box's CPU quota."""
+    from oracle import mil as omil
+    p0 = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(7)
+    bags = [torch.randn(N, D, generator=g) + 0.25 * (i % C) for i in range(64)]
+    default_threads, threads = torch.get_num_threads(), host_threads()
+
+    def run(nthreads, warm, n_steps, budget):
+        torch.set_num_threads(nthreads)
+        q = {k: torch.nn.Parameter(v.clone()) for k, v in p0.items()}
+        opt = torch.optim.AdamW(list(q.values()), lr=2.2e-4, weight_decay=8.6e-4)
+
+        def one(i):
+            opt.zero_grad()
+            out = omil.teacher_forward(q, bags[i % len(bags)], drop={"p": 0.5, "seed": 42, "stream": i * 1024})
+            omil.bag_loss(out["bag_logits"], torch.tensor(i % C)).backward()
+            opt.step()
+        for i in range(warm):
+            one(i)
+        t0 = time.perf_counter()
+        done = 0
+        for i in range(n_steps):
+            one(warm + i)
+            done += 1
+            if done >= 200 and time.perf_counter() - t0 > budget:
+                break
+        dt = time.perf_counter() - t0
+        torch.set_num_threads(default_threads)
+        return done / dt, done
+    v_all, d_all = run(threads, 30, 2000, budget_s / 2)
+    v_one, d_one = run(1, 30, 2000, budget_s / 2)
+    best, cores, done = (v_one, 1, d_one) if v_one >= v_all else (v_all, threads, d_all)
+    return {"value": best, "unit": "bags/s", "cores": cores, "kind": "port",
+            "sample": f"{done} per-bag train steps (one 196 x 768 bag per optimizer step, dropout 0.5 from the shared Philox "
+                      f"stream, fp32, torch CPU, {cores} thread(s)) after 30 warm-up steps",
+            "all_threads": {"value": v_all, "cores": threads, "sample": f"{d_all} steps after 30 warm-up steps"},
+            "one_thread": {"value": v_one, "cores": 1, "sample": f"{d_one} steps after 30 warm-up steps"},
+            "host_cpus": os.cpu_count()}
+
+
+# ----------------------------------------------------------------------------------------------- the adjacency build of 03
+WORKLOAD_KNN = ("k-NN adjacency build of 03_build_graphs.py:37-54 on 196 x 768 fp32 patch embeddings: the ten k values of "
+                "03:104-105 (1..8, 12, 16) for every image, from ONE distance matrix + top-16 per image")
+
+
+def run_knn(args, world, rank, dev):
+    """One step = the ten k-NN edge lists (k = 1..8, 12, 16; `03_build_graphs.py:8-9,104-105`) of ``--knn-graphs-per-step``
+    images: one isic_knn_graph launch (distance products on the fp32 matrix core + top-16 per node), then the ten
+    ``edge_index[G, 2, 196 k]`` tensors (a smaller k is a prefix of the top-16).  Ranks are independent (03 is embarrassingly
+    parallel over images: no exchange step)."""
+    import build_graphs as bg
+    import pipeline
+    from isic_hip.bags import BagOffsets
+    from isic_hip.graph import knn_indices
+    N, D = args.nodes, args.feat
+    G_ = args.knn_graphs_per_step
+    ks = [int(k) for k in bg.DEFAULT_K_VALUES]
+    gen = torch.Generator(device=dev).manual_seed(4321 + rank)
+    n_sets = 2
+    xs = [torch.randn(G_, N, D, device=dev, generator=gen) for _ in range(n_sets)]
+    offs = BagOffsets.uniform(G_, N, dev)
+    src = {k: torch.arange(N, device=dev).view(1, N, 1).expand(G_, N, k).reshape(G_, -1) for k in ks}
+    timer = KernelTimer.get()
+
+    def step(i):
+        nn = knn_indices(xs[i % n_sets].view(-1, D), offs, max(ks)).view(G_, N, max(ks))
+        return {k: torch.stack([src[k], nn[:, :, :k].reshape(G_, -1)], dim=1) for k in ks}      # 03:52-53, source-major
+
+    def step_k8(i):
+        nn = knn_indices(xs[i % n_sets].view(-1, D), offs, 8).view(G_, N, 8)
+        return torch.stack([src[8], nn.reshape(G_, -1)], dim=1)
+    for i in range(2 + args.warmup):
+        step(i)
+        step_k8(i)
+    elapsed, host_s, _ = timed_region(step, args, world, dev, timer, ["isic_knn_graph"], 0)
+    rec = timer.stop()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step_k8(i)
+    torch.cuda.synchronize()
+    k8_elapsed = time.perf_counter() - t0
+    if rank != 0:
+        return None
+    ms = sum(m for _n, _a, m in rec)
+    fl = 2.0 * N * N * D * G_ * len(rec)                       # SURVEY.md 8d: 2 N^2 D per image (59 MFLOP at 196 x 768)
+    achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    line = base_line("graphs/sec (k-NN adjacency build, all ten k of 03_build_graphs.py) @ 196x768 patch embeddings",
+                     "graphs/s", world * G_ * args.steps / elapsed, world, args, elapsed, "f32")
+    line["config"] = {"workload": WORKLOAD_KNN, "graphs_per_step_per_gpu": G_, "nodes": N, "feat": D, "k_values": ks,
+                      "parallelism": f"replicas{world}", "host_enqueue_ms_per_step": host_s * 1e3 / args.steps,
+                      "k8_only_graphs_per_s": world * G_ * args.steps / k8_elapsed}
+    line["roofline"] = {
+        "bound": "mfma", "kernel": "C-ABI entry isic_knn_graph (row norms + per-image distance products x x^T on "
+                                   "v_mfma_f32_16x16x4_f32 + top-16 selection, one launch per step)",
+        "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+        "traffic": None, "launches": len(rec), "avg_launch_ms": ms / max(len(rec), 1),
+        "algorithmic_gflop_per_launch": fl / max(len(rec), 1) / 1e9,
+        "algorithmic_bytes_per_launch": G_ * (N * D * 4 + N * 16 * 8),
+        "share_of_step_time": ms * 1e-3 / elapsed, "measured": "HIP events inside the timed region",
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import graphs as ograph
+        default_threads, threads = torch.get_num_threads(), host_threads()
+        xc = xs[0][:64].cpu()
+
+        def run(nthreads, budget):
+            torch.set_num_threads(nthreads)
+            for g in range(4):
+                ograph.knn_edge_index(xc[g], 8)
+            t0, done = time.perf_counter(), 0
+            while done < 2000 and (done < 200 or time.perf_counter() - t0 < budget):
+                for k in ks:                                   # the reference recomputes the distances for every k (03:104-105)
+                    ograph.knn_edge_index(xc[done % 64], k)
+                done += 1
+            dt = time.perf_counter() - t0
+            torch.set_num_threads(default_threads)
+            return done / dt, done
+        v_all, d_all = run(threads, args.cpu_budget_s / 2)
+        v_one, d_one = run(1, args.cpu_budget_s / 2)
+        best, cores, done = (v_one, 1, d_one) if v_one >= v_all else (v_all, threads, d_all)
+        line["cpu_baseline"] = {"value": best, "unit": "graphs/s", "cores": cores, "kind": "port",
+                                "sample": f"{done} images x the ten k values (oracle/graphs.knn_edge_index = 03:37-54 per k, fp32, "
+                                          f"torch CPU, {cores} thread(s)) after 4 warm-up images",
+                                "all_threads": {"value": v_all, "cores": threads, "sample": f"{d_all} images"},
+                                "one_thread": {"value": v_one, "cores": 1, "sample": f"{d_one} images"},
+                                "host_cpus": os.cpu_count()}
+    return line
 
 
 def host_threads():
@@ -678,7 +923,7 @@ def base_line(metric, unit, value, world, args, elapsed, dtype):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", choices=("mil", "gnn", "vit"), default="mil")
+    ap.add_argument("--config", choices=("mil", "gnn", "vit", "teacher", "knn"), default="mil")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
@@ -688,6 +933,10 @@ def main():
     ap.add_argument("--radiomics-dim", type=int, default=128)
     ap.add_argument("--graphs-per-step", type=int, default=256, help="gnn: graphs per optimizer step PER GPU")
     ap.add_argument("--images-per-step", type=int, default=2048, help="vit: images per forward PER GPU")
+    ap.add_argument("--teacher-bags-per-step", type=int, default=256, help="teacher: bags of 196 x 768 latents per step PER GPU")
+    ap.add_argument("--teacher-hidden", type=int, default=128)
+    ap.add_argument("--teacher-att", type=int, default=64)
+    ap.add_argument("--knn-graphs-per-step", type=int, default=2048, help="knn: images per adjacency-build step PER GPU")
     ap.add_argument("--nodes", type=int, default=196)
     ap.add_argument("--feat", type=int, default=768)
     ap.add_argument("--hidden", type=int, default=128)
@@ -733,15 +982,24 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    runners = {"mil": run_mil, "gnn": run_gnn, "vit": run_vit}
+    def run_teacher_both(a, w, r, d):
+        """the reference's default head (H128 / A64) with its tuned head (H368 / A772) attached as `tuned`"""
+        line = run_teacher(a, w, r, d)
+        release_device_memory()
+        tuned = run_teacher(a, w, r, d, H=368, A=772)
+        if r == 0:
+            line["tuned"] = tuned
+        return line
+    runners = {"mil": run_mil, "gnn": run_gnn, "vit": run_vit, "teacher": run_teacher_both, "knn": run_knn}
     line = runners[args.config](args, world, rank, dev)
     if args.config == "mil" and not args.no_sublines:
         # BASELINE.json configs[3] and configs[4] ride on the SAME line (the driver parses one line): short runs of the
-        # graph step and of the ViT encoder, each with its own roofline and cpu_baseline
+        # graph step and of the ViT encoder, then the reference's OWN hot loop (the teacher step on resident latents) and the
+        # adjacency build of 03, each with its own roofline and cpu_baseline
         sub_args = argparse.Namespace(**vars(args))
         sub_args.steps, sub_args.warmup = args.sub_steps, 3
-        sub_args.cpu_budget_s = min(args.cpu_budget_s, 12.0)
-        for name in ("gnn", "vit"):
+        sub_args.cpu_budget_s = min(args.cpu_budget_s, 10.0)
+        for name in ("gnn", "vit", "teacher", "knn"):
             release_device_memory()
             try:
                 sub = runners[name](sub_args, world, rank, dev)
@@ -775,12 +1033,7 @@ def self_launch(args):
     are new processes (subprocess), never an exec of this one."""
     import socket
     import subprocess
-    n = args.gpus
-    if not args.rehearse_on_one_gpu:
-        have = torch.cuda.device_count()            # counts devices without initialising the runtime
-        if have < n:
-            print(f"bench.py: --gpus {n} but {have} GPU(s) visible", file=sys.stderr)
-            return 2
+    n = args.gpus          # the parent never asks the runtime anything: a child whose device is missing exits non-zero
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]

@@ -118,8 +118,9 @@ int isic_multi_copy_f32(int nseg, float* const* dst, const float* const* src, co
  *                               `counter`: one zero uint32 (left zero); dropout as isic_relu_dropout_fwd_clk_f32 on [B, D];
  *   isic_graph_head_param_grads: dW1[D, H], db1[D], dW2[C, D], db2[C] (+= when accumulate) = grad_scale[0] (device scalar,
  *                               NULL = 1) * the contributions added in block order.  C <= 15. */
-/* 1 when the fused head handles the shape (C < 16 and W1 twice + the row tiles fit 160 KB of LDS: H * D <= ~19 k, e.g.
- * H = D = 128), else 0: the caller then runs the operator chain (isic_gemm_f32 / isic_softmax_rows / isic_cross_entropy). */
+/* ISIC_OK when the fused head handles the shape (C < 16 and W1 twice + the row tiles fit 160 KB of LDS: H * D <= ~19 k,
+ * e.g. H = D = 128), else ISIC_ERR_UNSUPPORTED: the caller then runs the operator chain (isic_gemm_f32 /
+ * isic_softmax_rows / isic_cross_entropy). */
 int isic_graph_head_supported(int H, int D, int C);
 size_t isic_graph_head_workspace_bytes(int B, int H, int D, int C);
 int isic_graph_head_fwd_bwd(const float* z, const float* W1, const float* b1, const float* W2, const float* b2,

@@ -224,8 +224,9 @@ size_t head_lds_bytes(int H, int D, int C) {
 extern "C" {
 
 int isic_graph_head_supported(int H, int D, int C) {
-  if (H <= 0 || D <= 0 || C <= 0 || C >= MAXC) return 0;
-  return head_lds_bytes(H, D, C) <= 160 * 1024 - 256 ? 1 : 0;   // (the kernel has a few static bytes of its own)
+  ISIC_CHECK_ARG(H > 0 && D > 0 && C > 0);
+  if (C >= MAXC) return ISIC_ERR_UNSUPPORTED;
+  return head_lds_bytes(H, D, C) <= 160 * 1024 - 256 ? ISIC_OK : ISIC_ERR_UNSUPPORTED;   // (the kernel has a few static bytes of its own)
 }
 
 size_t isic_graph_head_workspace_bytes(int B, int H, int D, int C) {
@@ -240,7 +241,7 @@ int isic_graph_head_fwd_bwd(const float* z, const float* W1, const float* b1, co
                             void* stream) {
   ISIC_CHECK_ARG(B > 0 && H > 0 && D > 0 && C > 0);
   ISIC_CHECK_ARG(z && W1 && b1 && W2 && b2 && labels && probs && loss_per_sample && loss_mean && dz && workspace && counter);
-  if (!isic_graph_head_supported(H, D, C)) return ISIC_ERR_UNSUPPORTED;
+  if (isic_graph_head_supported(H, D, C) != ISIC_OK) return ISIC_ERR_UNSUPPORTED;
   const size_t lds = head_lds_bytes(H, D, C);
   if (workspace_bytes < isic_graph_head_workspace_bytes(B, H, D, C) || (reinterpret_cast<uintptr_t>(workspace) & 15))
     return ISIC_ERR_WORKSPACE;

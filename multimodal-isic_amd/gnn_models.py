@@ -217,6 +217,17 @@ class GraphMIL(nn.Module):
         """CSR aggregation mode the layers need (``GraphBatch`` mode), ``None`` for the graph-free 'mlp'."""
         return _GRAPH_MODE.get(self.gnn_type)
 
+    def _gcnii_weight(self, i, layer):
+        """GCN2Conv's effective weight ((1 - beta) I + beta W1)^T: the scaled identity is a constant of the layer, built once
+        per device (no ``torch.eye`` per call); the one ``torch.add`` left carries the gradient into ``weight1``."""
+        cache = self.__dict__.setdefault("_gcnii_eye", {})
+        key = (i, layer.weight1.device)
+        e = cache.get(key)
+        if e is None:
+            e = cache[key] = (1.0 - layer.beta) * torch.eye(layer.weight1.shape[0], device=layer.weight1.device,
+                                                            dtype=torch.float32)
+        return torch.add(e, layer.weight1, alpha=layer.beta).t()
+
     def _graph(self, edge_index, edge_weight, n_nodes, graph):
         if self.gnn_type == 'mlp':
             return None
@@ -292,9 +303,7 @@ class GraphMIL(nn.Module):
                 h = ops.linear(z1, layer.nn[2].weight, layer.nn[2].bias)
             else:  # gcnii: (1-beta) p + beta p W1 with p = (1-alpha) A^ h + alpha x0  ==  p @ ((1-beta) I + beta W1)
                 p = spmm(h, g, alpha=1.0 - layer.alpha, addend=x0, addend_scale=layer.alpha)
-                eye = torch.eye(layer.weight1.shape[0], device=p.device, dtype=torch.float32)
-                w_eff = (1.0 - layer.beta) * eye + layer.beta * layer.weight1
-                h = ops.linear(p, w_eff.t(), None)
+                h = ops.linear(p, self._gcnii_weight(i, layer), None)
             res = h_prev if (self.use_residual and h_prev.shape == h.shape) else None
             if self.use_layer_norm:
                 ln = self.layer_norms[i]

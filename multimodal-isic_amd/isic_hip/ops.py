@@ -606,7 +606,13 @@ class GraphHeadLossFn(torch.autograd.Function):
 
 def graph_head_supported(H, D, C):
     """Whether ``graph_head_loss`` handles Linear(H, D) -> Linear(D, C) (LDS bound, C < 16); else use the operator chain."""
-    return bool(call("isic_graph_head_supported", int(H), int(D), int(C)))
+    try:
+        call("isic_graph_head_supported", int(H), int(D), int(C))
+        return True
+    except IsicHipError as e:
+        if e.code != ERR_UNSUPPORTED:
+            raise
+        return False
 
 
 def graph_head_loss(z, W1, b1, W2, b2, labels, drop=None):
