@@ -20,11 +20,18 @@ extern "C" {
  *            0 shipped default, 1 never, 2 wherever the kernel supports the shape
  *   thousands persistent short-K kernel (conv_pgemm.hip: strided 3x3, its data gradient, 1x1 downsample):
  *            0 shipped default, 1 never, 2 wherever the kernel supports the shape (Cout % 128 == 0)
+ *   ten-thousands  a kernel-internal A/B experiment of conv_halo.hip (0 = shipped code; tools/halo_ab.py)
  * variant = 0 is exactly isic_conv2d_igemm_bf16. */
 int isic_test_conv2d_igemm_variant_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int Hin, int Win,
                                         int Cin, int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad,
                                         const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots,
                                         int variant, void* stream);
+
+/* isic_conv2d_wgrad_bf16 (same arguments) with `variant`: 0 = shipped; 1 = the all-taps kernel of the >= 128-channel 3x3
+ * layers (conv_wgrad_c128.hip) with the block order it does NOT ship with (XCD-grouped co-slice blocks vs pair-major). */
+int isic_test_conv2d_wgrad_variant_bf16(const uint16_t* x, const uint16_t* dy, float* dw, int N, int Hin, int Win, int Cin,
+                                        int Hout, int Wout, int Cout, int Kh, int Kw, int stride, int pad, void* workspace,
+                                        size_t workspace_bytes, int variant, void* stream);
 
 /* isic_gemm_f32_ws (same arguments) with the kernel pinned: variant 0 = shipped choice, 1 = always the 64 x 64 x 16
  * register-staged kernel (split-K through fp32 atomics), 2 = the persistent 256 x 128 x 32 kernel or

@@ -96,12 +96,19 @@ __device__ unsigned long long g_halo_stamps[256 * 64 * 4];
 // applies the ReLU mask (1 bit per value, written by the forward), stores dz = mask ? g : 0 and accumulates the two
 // sums BatchNorm's backward needs, sum dz and sum dz * y, per channel -- the separate reduction pass over (g, y) and,
 // for a block's last BatchNorm, the materialised residual gradient (= dz) disappear.
-template <int STATS, bool ADDEND>
+//
+// KPB = K-tiles per barrier.  1: the three-stage weight ring above.  2: FOUR weight stages and one barrier per TWO K-tiles
+// (64 MFMAs per wave between barriers): after barrier S the staging waves fetch the two K-tiles of step S + 1 into the
+// two stages step S - 1 used and wait for ALL their own DMAs (vmcnt(0): no dummy pieces) in front of barrier S + 1.
+// The next chunk's patch pieces go out at taps 1..6 (not 0..5): a step may hold (chunk c - 1, tap 8) and (chunk c, tap 0),
+// and the buffer of chunk c + 1 is the one chunk c - 1 reads.  Needs Cin % 128 == 0 (an even number of K-tiles per tile).
+template <int STATS, bool ADDEND, int KPB, int PRIO>
 __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  constexpr int NST = KPB == 2 ? 4 : NWST;
   const int PB = a.prows * 128;
-  const int off_w = 2 * PB, off_zero = off_w + NWST * WSTAGE, off_scr = off_zero + 128, off_stat = off_scr + 1024;
+  const int off_w = 2 * PB, off_zero = off_w + NST * WSTAGE, off_scr = off_zero + 128, off_stat = off_scr + 1024;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -147,6 +154,46 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
       halo_glds16(live ? (const void*)(s0 + (size_t)16 * 9 * a.Cin) : (const void*)zp, live ? dst + 1024 : scr);
     };
 
+    if constexpr (KPB == 2) {
+      // ---- one barrier per two K-tiles, four weight stages, every DMA of a step waited for before the next barrier
+      auto piece2 = [&](int j, int tl, int cc, int buf) {    // as patch_piece, but nothing is issued for a dead piece
+        const int g = sw + 8 * j;
+        if (g >= groups) return;
+        const long long pix = (long long)(t_begin + tl) * HM - (a.W + 1) + g * 8 + r8;
+        const bool ok = pix >= 0 && pix < a.M;
+        halo_glds16(ok ? (const void*)(a.in + (size_t)pix * a.Cin + cc * 64 + gch * 8) : (const void*)zp,
+                    lds0 + (unsigned)(buf * PB + g * 1024));
+      };
+      auto weights2 = [&](int tap, int cc, int stage) {
+        const unsigned short* s0 = wrow + (size_t)tap * a.Cin + cc * 64;
+        const unsigned dst = lds0 + off_w + stage * WSTAGE + sw * 2048;
+        halo_glds16((const void*)s0, dst);
+        halo_glds16((const void*)(s0 + (size_t)16 * 9 * a.Cin), dst + 1024);
+      };
+#pragma unroll
+      for (int j = 0; j < MAX_PPW; ++j) piece2(j, 0, 0, 0);
+      weights2(0, 0, 0);
+      weights2(1, 0, 1);
+      const int total_kt = total_chunks * 9;                 // even (Cin % 128 == 0)
+      // (tap, chunk, tile, chunk counter) of the K-tile whose patch pieces are issued: the CURRENT step's K-tiles;
+      // (tap, chunk) of the K-tile whose weights are issued: two K-tiles ahead
+      int ptap = 0, pcc = 0, ptl = 0, pgc = 0;
+      int wtap = 2, wcc = 0;
+      for (int g = 0; g < total_kt; g += 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (g + 2 + h < total_kt) weights2(wtap, wcc, (g + 2 + h) & 3);
+          if (++wtap == 9) { wtap = 0; if (++wcc == a.cchunks) wcc = 0; }
+          if (ptap >= 1 && ptap <= MAX_PPW && pgc + 1 < total_chunks) {
+            const bool last = pcc + 1 == a.cchunks;
+            piece2(ptap - 1, last ? ptl + 1 : ptl, last ? 0 : pcc + 1, (pgc + 1) & 1);
+          }
+          if (++ptap == 9) { ptap = 0; ++pgc; if (++pcc == a.cchunks) { pcc = 0; ++ptl; } }
+        }
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < MAX_PPW; ++j) patch_piece(j, 0, 0, 0, true);
     weights(0, 0, 0, true);
@@ -178,6 +225,7 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
         }
       }
     }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may outlive the block's LDS allocation
   } else {
   // ===================================================================== MFMA waves
@@ -192,7 +240,8 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
   const unsigned boff0 = (unsigned)((wn * 64 + fr) * 128 + ((fg ^ (fr & 7)) << 4));
   const int prow0 = wm * 64 + fr;                        // patch row of tap (0, 0) of this lane's first pixel
 
-  int gc = 0;
+  if (PRIO) __builtin_amdgcn_s_setprio(PRIO);             // the multiplying waves win vector-issue arbitration against the staging waves
+  int gc = 0, gkt = 0;
   for (int tl = 0; tl < ntl; ++tl) {
     const int m0 = (t_begin + tl) * HM;
     // this lane's four pixels: tap validity (bit tap) and the patch row of tap (0, 0)
@@ -220,6 +269,43 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     HALO_STAMP(tl, 0);                                     // tile set-up done, K loop starts
 
+    if constexpr (KPB == 2) {
+      int tap = 0, kh = 0, kw = 0;
+      const int nkt = a.cchunks * 9;
+#pragma unroll 1
+      for (int kt = 0; kt < nkt; kt += 2) {
+        __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {                      // (not unrolled: hipcc otherwise hoists the second K-tile's fragment
+          const int pbase = (gc & 1) * PB;                 //  reads over the first one's multiplies and spills)
+          const unsigned char* wst = smem + off_w + ((gkt + h) & 3) * WSTAGE;
+          const int toff = kh * a.W + kw;
+          unsigned aoff[4];
+          const int p = prow0 + toff;
+          const int real0 = pbase + p * 128 + ((fg ^ (p & 7)) << 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) aoff[i] = (unsigned)(((vmask[i] >> tap) & 1u) ? real0 + i * 2048 : off_zero);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              af[i] = *reinterpret_cast<const bf16x8*>(smem + (aoff[i] ^ (unsigned)(ks << 6)));
+              bfr[i] = *reinterpret_cast<const bf16x8*>(wst + ((boff0 ^ (unsigned)(ks << 6)) + i * 2048));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          }
+          ++tap;
+          if (++kw == 3) { kw = 0; ++kh; }
+          if (tap == 9) { tap = 0; kh = 0; ++gc; }
+        }
+        gkt += 2;
+      }
+    } else {
     for (int cc = 0; cc < a.cchunks; ++cc, ++gc) {
       const int pbase = (gc & 1) * PB;
 #pragma unroll 1
@@ -253,6 +339,7 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
       }
     }
 
+    }
     HALO_STAMP(tl, 1);                                     // K loop issued
     // ---- register-only epilogue: lane (fg, fr) holds, for MFMA tiles (i, 2t) and (i, 2t+1), the eight consecutive
     //      output channels n0 + wn*64 + 32t + 8fg + {0..7} of pixel m0 + wm*64 + i*16 + fr: one 16-byte access each.
@@ -448,15 +535,15 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
   }
 }
 
-template <int STATS, bool ADDEND>
+template <int STATS, bool ADDEND, int KPB, int PRIO>
 int launch_halo(const HaloArgs& a, int grid, int lds, hipStream_t stream) {
   static IsicPerDeviceOnce once;              // hipFuncSetAttribute is per device (one flag set per template instance)
   if (isic_once_per_device(once, [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<STATS, ADDEND>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MAX_PROWS * 128 + NWST * WSTAGE + 2176 + 3072);
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<STATS, ADDEND, KPB, PRIO>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       }) != hipSuccess)
     return ISIC_ERR_LAUNCH;
-  hipLaunchKernelGGL((conv_halo_kernel<STATS, ADDEND>), dim3(grid), dim3(1024), lds, stream, a);
+  hipLaunchKernelGGL((conv_halo_kernel<STATS, ADDEND, KPB, PRIO>), dim3(grid), dim3(1024), lds, stream, a);
   return ISIC_OK;
 }
 
@@ -471,7 +558,7 @@ bool isic_conv_halo_supported(int N, int H, int W, int Cin, int Cout) {
 
 int isic_conv_halo_launch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int H, int W, int Cin, int Cout,
                           const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots,
-                          const uint8_t* relu_mask, const uint16_t* yraw, hipStream_t stream) {
+                          const uint8_t* relu_mask, const uint16_t* yraw, int experiment, hipStream_t stream) {
   if (!isic_conv_halo_supported(N, H, W, Cin, Cout)) return ISIC_ERR_UNSUPPORTED;
   const int cus = isic_cu_count();
   HaloArgs a;
@@ -489,14 +576,30 @@ int isic_conv_halo_launch(const uint16_t* in, const uint16_t* w, uint16_t* out, 
   a.prows = ceil_div(HM + 2 * W + 2, 8) * 8;
   a.magic_hw = ((1ULL << 40) / (unsigned long long)(H * W)) + 1;
   a.magic_w = ((1ULL << 40) / (unsigned long long)W) + 1;
-  const int lds = 2 * a.prows * 128 + NWST * WSTAGE + 2176 + 3072;     // statistics: 1 KB (forward) or 4 KB (STATS 2)
+  int lds = 2 * a.prows * 128 + NWST * WSTAGE + 2176 + 3072;     // statistics: 1 KB (forward) or 4 KB (STATS 2)
   const int grid = a.groups * a.nslices;
+  const int lds2 = lds + WSTAGE;                             // KPB = 2: a fourth weight stage
+  const bool kpb2_ok = Cin % 128 == 0 && lds2 <= 160 * 1024;
+  if (experiment && !(relu_mask || yraw)) {                  // A/B experiments (include/isic_hip_test.h): 1 = PRIO, 2 = KPB 2, 3 = both
+    if ((experiment & 2) && !kpb2_ok) return ISIC_ERR_UNSUPPORTED;
+    if (stat_sum && addend) return ISIC_ERR_UNSUPPORTED;
+    if (stat_sum) {
+      if (experiment == 1) return launch_halo<1, false, 1, 1>(a, grid, lds, stream);
+      if (experiment == 2) return launch_halo<1, false, 2, 0>(a, grid, lds2, stream);
+      if (experiment == 3) return launch_halo<1, false, 2, 1>(a, grid, lds2, stream);
+    } else if (!addend) {
+      if (experiment == 1) return launch_halo<0, false, 1, 1>(a, grid, lds, stream);
+      if (experiment == 2) return launch_halo<0, false, 2, 0>(a, grid, lds2, stream);
+      if (experiment == 3) return launch_halo<0, false, 2, 1>(a, grid, lds2, stream);
+    }
+    return ISIC_ERR_UNSUPPORTED;
+  }
   if (relu_mask || yraw) {                                 // data gradient feeding a BatchNorm backward (STATS 2)
     if (!relu_mask || !yraw || !stat_sum || !stat_sumsq) return ISIC_ERR_BAD_ARG;
-    return addend ? launch_halo<2, true>(a, grid, lds, stream) : launch_halo<2, false>(a, grid, lds, stream);
+    return addend ? launch_halo<2, true, 1, 0>(a, grid, lds, stream) : launch_halo<2, false, 1, 0>(a, grid, lds, stream);
   }
   if (stat_sum && addend) return ISIC_ERR_UNSUPPORTED;
-  if (stat_sum) return launch_halo<1, false>(a, grid, lds, stream);
-  if (addend) return launch_halo<0, true>(a, grid, lds, stream);
-  return launch_halo<0, false>(a, grid, lds, stream);
+  if (stat_sum) return launch_halo<1, false, 1, 0>(a, grid, lds, stream);
+  if (addend) return launch_halo<0, true, 1, 0>(a, grid, lds, stream);
+  return launch_halo<0, false, 1, 0>(a, grid, lds, stream);
 }

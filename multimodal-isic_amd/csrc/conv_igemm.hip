@@ -408,7 +408,7 @@ int isic_conv3x3_c64_launch(int variant, const uint16_t* in, const uint16_t* w, 
 bool isic_conv_halo_supported(int N, int H, int W, int Cin, int Cout);
 int isic_conv_halo_launch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int H, int W, int Cin, int Cout,
                           const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots, const uint8_t* relu_mask,
-                          const uint16_t* yraw,
+                          const uint16_t* yraw, int experiment,
                           hipStream_t stream);
 int isic_conv_pgemm_launch(const isic_conv::ConvArgsN& classes, hipStream_t stream);
 
@@ -421,7 +421,7 @@ namespace {
 //   profitable: strided and 1x1 layers, 1 = never, 2 = wherever it is supported).  No global state: the choice travels
 //   with the call.
 struct ConvVariant {
-  int mode, c64, halo, pgemm;
+  int mode, c64, halo, pgemm, exp;
 };
 inline ConvVariant decode_variant(int v) {
   ConvVariant r;
@@ -430,6 +430,7 @@ inline ConvVariant decode_variant(int v) {
   r.c64 = c == 0 ? kDefaultConvC64 : c - 1;
   r.halo = (v / 100) % 10;
   r.pgemm = (v / 1000) % 10;
+  r.exp = (v / 10000) % 10;          // ten-thousands: a kernel-internal A/B experiment (0 = shipped code)
   return r;
 }
 
@@ -447,7 +448,7 @@ int conv2d_dispatch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N,
                     const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots, int variant,
                     void* stream) {
   ISIC_CHECK_ARG(in && w && out);
-  ISIC_CHECK_ARG(variant >= 0 && variant < 10000);
+  ISIC_CHECK_ARG(variant >= 0 && variant < 100000);
   const ConvVariant cv = decode_variant(variant);
   ISIC_CHECK_ARG(cv.mode >= 0 && cv.mode <= 5 && cv.c64 >= 0 && cv.c64 <= 2 && cv.halo >= 0 && cv.halo <= 2 &&
                  cv.pgemm >= 0 && cv.pgemm <= 2);
@@ -468,7 +469,7 @@ int conv2d_dispatch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N,
   if (same3x3 && cv.halo != 1 && !(stat_sum && addend) && isic_conv_halo_supported(N, Hin, Win, Cin, Cout) &&
       (cv.halo == 2 || Cin >= 128)) {
     const int rc = isic_conv_halo_launch(in, w, out, N, Hin, Win, Cin, Cout, addend, stat_sum, stat_sumsq, stat_slots,
-                                         nullptr, nullptr, as_stream(stream));
+                                         nullptr, nullptr, cv.exp, as_stream(stream));
     return rc != ISIC_OK ? rc : isic_launch_status();
   }
   ConvArgs a;
@@ -569,7 +570,7 @@ int isic_conv2d_dgrad_bnbwd_bf16(const uint16_t* in, const uint16_t* w, uint16_t
   ISIC_CHECK_ARG(in && w && out && relu_mask && y_raw && sum_dz && sum_dzy && stat_slots > 0);
   if (!isic_conv2d_dgrad_bnbwd_supported(N, Hin, Win, Cin, Hout, Wout, Cout, Kh, Kw, up, down, pad)) return ISIC_ERR_UNSUPPORTED;
   const int rc = isic_conv_halo_launch(in, w, out, N, Hin, Win, Cin, Cout, addend, sum_dz, sum_dzy, stat_slots, relu_mask,
-                                       y_raw, as_stream(stream));
+                                       y_raw, 0, as_stream(stream));
   return rc != ISIC_OK ? rc : isic_launch_status();
 }
 

@@ -285,13 +285,20 @@ int isic_wgrad_c64_launch(const uint16_t* x, const uint16_t* dy, float* dw, int 
 // ... and of the 3x3 layers with Cin % 128 == 0, Cout % 32 == 0: 128, 256, 512 channels (conv_wgrad_c128.hip)
 size_t isic_wgrad_c128_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int isic_wgrad_c128_launch(const uint16_t* x, const uint16_t* dy, float* dw, int N, int H, int W, int Cin, int Cout,
-                           void* workspace, hipStream_t stream);
+                           void* workspace, int xcd_group, hipStream_t stream);
 
 namespace {
 // the all-taps kernels are always used for the shapes they cover (no environment switches, no global state)
 inline bool wgrad_c128_enabled() { return true; }
+constexpr int kWgradC128XcdGroup = 0;      // shipped block order of conv_wgrad_c128.hip (A/B: tools/halo_ab.py --wgrad)
 inline bool wgrad_c64_enabled() { return true; }
 }  // namespace
+
+namespace {
+int conv2d_wgrad_dispatch(const uint16_t* x, const uint16_t* dy, float* dw, int N, int Hin, int Win, int Cin,
+                          int Hout, int Wout, int Cout, int Kh, int Kw, int stride, int pad, void* workspace,
+                          size_t workspace_bytes, int variant, void* stream);
+}
 
 extern "C" {
 
@@ -313,6 +320,25 @@ size_t isic_conv2d_wgrad_workspace_bytes(int N, int Cin, int Hout, int Wout, int
 int isic_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dw, int N, int Hin, int Win, int Cin,
                            int Hout, int Wout, int Cout, int Kh, int Kw, int stride, int pad, void* workspace,
                            size_t workspace_bytes, void* stream) {
+  return conv2d_wgrad_dispatch(x, dy, dw, N, Hin, Win, Cin, Hout, Wout, Cout, Kh, Kw, stride, pad, workspace, workspace_bytes,
+                               0, stream);
+}
+
+int isic_test_conv2d_wgrad_variant_bf16(const uint16_t* x, const uint16_t* dy, float* dw, int N, int Hin, int Win, int Cin,
+                                        int Hout, int Wout, int Cout, int Kh, int Kw, int stride, int pad, void* workspace,
+                                        size_t workspace_bytes, int variant, void* stream) {
+  return conv2d_wgrad_dispatch(x, dy, dw, N, Hin, Win, Cin, Hout, Wout, Cout, Kh, Kw, stride, pad, workspace, workspace_bytes,
+                               variant, stream);
+}
+
+}  // extern "C"
+
+namespace {
+
+// variant (include/isic_hip_test.h): 0 = shipped; 1 = the all-taps >= 128-channel kernel with the OTHER block order
+int conv2d_wgrad_dispatch(const uint16_t* x, const uint16_t* dy, float* dw, int N, int Hin, int Win, int Cin,
+                          int Hout, int Wout, int Cout, int Kh, int Kw, int stride, int pad, void* workspace,
+                          size_t workspace_bytes, int variant, void* stream) {
   ISIC_CHECK_ARG(x && dy && dw && workspace);
   ISIC_CHECK_ARG(N > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && Kh > 0 && Kw > 0 && stride > 0 && pad >= 0);
   ISIC_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0);
@@ -334,7 +360,8 @@ int isic_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dw, int
     const size_t need = isic_wgrad_c128_workspace_bytes(N, Hin, Win, Cin, Cout);
     if (need != 0) {
       if (workspace_bytes < need) return ISIC_ERR_WORKSPACE;
-      const int rc = isic_wgrad_c128_launch(x, dy, dw, N, Hin, Win, Cin, Cout, workspace, as_stream(stream));
+      const int rc = isic_wgrad_c128_launch(x, dy, dw, N, Hin, Win, Cin, Cout, workspace, kWgradC128XcdGroup ^ (variant & 1),
+                                            as_stream(stream));
       return rc != ISIC_OK ? rc : isic_launch_status();
     }
   }
@@ -364,4 +391,5 @@ int isic_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dw, int
   return isic_launch_status();
 }
 
-}  // extern "C"
+}  // namespace
+

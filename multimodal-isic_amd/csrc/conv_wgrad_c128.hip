@@ -44,6 +44,8 @@ struct WC128Args {
   int co_slices;                // Cy / 32
   int pack, slot_shift;         // images per tile row (1, 2, 4) and log2 of their slot width (5, 4, 3)
   int Wv;                       // width of the virtual image a tile row walks: W (pack 1) or 32
+  int pairs;                    // (Cx / 128) * (Cy / 32)
+  int xcd_group;                // 1: blocks that stage the SAME X tiles (one pixel range, every co slice) share an XCD's L2
 };
 
 __device__ __attribute__((aligned(256))) unsigned char g_wc128_zeros[2048];
@@ -59,7 +61,21 @@ __global__ __launch_bounds__(768) void wgrad_c128_kernel(WC128Args a) {
   typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int pair = blockIdx.x / a.blocks_per_slice, bs = blockIdx.x - pair * a.blocks_per_slice;
+  // block -> (pair, pixel range).  Hardware deals blocks round-robin over the 8 XCDs (b and b + 8 share an L2).  The X tiles
+  // of a pixel range are staged by EVERY co-slice block of that range (Cout / 32 of them: 4 / 8 / 16), the chip streams
+  // HBM -> LDS at only ~10 B/clk per CU but L2 -> LDS at 40-50 (tests/probes/probe_stage.hip), and at 63 KB per 2,304
+  // MFMA cycles the kernel asks for 27: with the co-slice blocks of a range on ONE XCD, walking their tiles in step (every
+  // block is resident: one per CU), X comes out of L2 for all but the first of them.  Logical order: range-major, pair fastest.
+  int pair, bs;
+  if (a.xcd_group) {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);     // bijective
+    bs = __builtin_amdgcn_readfirstlane(L / a.pairs);      // (integer division runs on the vector unit: back to a scalar)
+    pair = L - bs * a.pairs;
+  } else {
+    pair = blockIdx.x / a.blocks_per_slice;
+    bs = blockIdx.x - pair * a.blocks_per_slice;
+  }
   const int ci_slice = pair / a.co_slices, slice = pair - ci_slice * a.co_slices;      // slice: 32 output channels
   const int t_begin = bs * a.tiles_per_block;
   const int ntl = min(a.total_tiles - t_begin, a.tiles_per_block);       // >= 1 by construction of the grid
@@ -245,7 +261,7 @@ __global__ __launch_bounds__(768) void wgrad_c128_kernel(WC128Args a) {
   }
 
   // this block's partial: lane (fg, fi) holds D[ci = 16c + 4fg + r][co = 32 slice + 16 c2 + fi]
-  float* part = a.partial + (size_t)blockIdx.x * SLICE_ELEMS;
+  float* part = a.partial + ((size_t)pair * a.blocks_per_slice + bs) * SLICE_ELEMS;
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -309,7 +325,7 @@ size_t isic_wgrad_c128_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
 
 // called by isic_conv2d_wgrad_bf16 for 3x3, stride 1, pad 1, Cin % 128 == 0, Cout % 32 == 0
 int isic_wgrad_c128_launch(const uint16_t* x, const uint16_t* dy, float* dw, int N, int H, int W, int Cin, int Cout,
-                           void* workspace, hipStream_t stream) {
+                           void* workspace, int xcd_group, hipStream_t stream) {
   WC128Plan p;
   if (!wc128_plan(N, H, W, Cin, Cout, p)) return ISIC_ERR_UNSUPPORTED;
   WC128Args a;
@@ -317,6 +333,7 @@ int isic_wgrad_c128_launch(const uint16_t* x, const uint16_t* dy, float* dw, int
   a.N = N; a.H = H; a.W = W;
   a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x; a.total_tiles = p.total_tiles;
   a.tiles_per_block = p.tiles_per_block; a.blocks_per_slice = p.blocks_per_pair;
+  a.pairs = p.pairs; a.xcd_group = xcd_group;
   a.Cx = Cin; a.Cy = Cout; a.co_slices = Cout / 32; a.pack = p.pack; a.slot_shift = p.slot_shift; a.Wv = p.Wv;
   static IsicPerDeviceOnce once;              // hipFuncSetAttribute is per device (one flag set per template instance)
   if (isic_once_per_device(once, [] {

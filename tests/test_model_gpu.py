@@ -45,6 +45,11 @@ def test_fusion_net_golden(R, strat, level):
     for k in keys:
         gr = params[k].grad
         assert gr is not None, k
+        if k == "attention.attn.2.bias":
+            # analytically zero (the softmax over the modalities is invariant to a shift of every score): the reference itself
+            # holds 4.5e-8 of rounding noise here, and so does this path -- compared absolutely
+            assert float(gr.abs().max()) < 1e-6 and abs(float(g[f"grad.{k}"].reshape(-1)[0])) < 1e-6
+            continue
         check_grad(g, k, gr, rtol=3e-4, atol=1e-7)
     for k, prm in params.items():
         if k not in keys:

@@ -1,0 +1,103 @@
+"""A/B of kernel-internal experiments of the 3x3 convolution kernels (include/isic_hip_test.h, ten-thousands digit of
+`variant`) inside ONE process: bit-equality with the shipped kernel + HIP-event timing.  Developer tool:
+    python tools/halo_ab.py [--n 2048] [--exps 0,1,2,3] [--layers l2,l3,l4]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "multimodal-isic_amd"))
+import torch
+from isic_hip.lib import IsicHipError, call
+
+BF, DEV = torch.bfloat16, "cuda:0"
+LAYERS = {"l1": (64, 56), "l2": (128, 28), "l3": (256, 14), "l4": (512, 7)}
+
+
+def timeit(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def wgrad_ab(a):
+    N = a.n
+    for name in a.layers.split(","):
+        C, h = LAYERS[name]
+        x = torch.randn(N, h, h, C, device=DEV).to(BF)
+        dy = torch.randn(N, h, h, C, device=DEV).to(BF)
+        gf = 2.0 * N * h * h * C * 9 * C / 1e9
+        wsb = torch.empty(call("isic_conv2d_wgrad_workspace_bytes", N, C, h, h, C, 3, 3), device=DEV, dtype=torch.uint8)
+        ref = None
+        for v in (0, 1, 0, 1):
+            dw = torch.zeros(C, C, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last)
+
+            def run():
+                call("isic_test_conv2d_wgrad_variant_bf16", x, dy, dw, N, h, h, C, h, h, C, 3, 3, 1, 1, wsb, wsb.numel(), v)
+            run()
+            torch.cuda.synchronize()
+            if ref is None:
+                ref, same = dw.clone(), "ref"
+            else:
+                same = "bit-equal" if torch.equal(dw, ref) else f"DIFFERS max {float((dw - ref).abs().max()):.3e}"
+            t = timeit(run, a.iters)
+            print(f"{name} wgrad variant {v}: {t:7.4f} ms  {gf / t:7.0f} TF/s  {same}", flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=2048)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--exps", default="0,1,2,3")
+    ap.add_argument("--layers", default="l2,l3,l4")
+    ap.add_argument("--addend", action="store_true", help="also the data gradient with a residual-gradient addend")
+    ap.add_argument("--wgrad", action="store_true", help="A/B of the weight-gradient block orders instead (isic_test_conv2d_wgrad_variant_bf16)")
+    a = ap.parse_args()
+    if a.wgrad:
+        return wgrad_ab(a)
+    N = a.n
+    exps = [int(v) for v in a.exps.split(",")]
+    for name in a.layers.split(","):
+        C, h = LAYERS[name]
+        x = torch.randn(N, h, h, C, device=DEV).to(BF)
+        add = torch.randn(N, h, h, C, device=DEV).to(BF)
+        w = (torch.randn(C, C, 3, 3, device=DEV) / (C * 9) ** 0.5).contiguous(memory_format=torch.channels_last)
+        wf, wd = torch.empty(C * C * 9, device=DEV, dtype=BF), torch.empty(C * C * 9, device=DEV, dtype=BF)
+        call("isic_conv_weight_prep_bf16", w, wf, wd, C, C, 3, 3)
+        gf = 2.0 * N * h * h * C * 9 * C / 1e9
+        modes = [("fwd+stats", wf, True, None), ("dgrad", wd, False, None)] + ([("dgrad+addend", wd, False, add)] if a.addend else [])
+        for mode, wt, stats, ad in modes:
+            ref = None
+            for e in exps:
+                out = torch.zeros(N, h, h, C, device=DEV, dtype=BF)
+                acc = torch.zeros(2, 256, C, device=DEV, dtype=torch.float64)
+
+                def run():
+                    call("isic_test_conv2d_igemm_variant_bf16", x, wt, out, N, h, h, C, h, h, C, 3, 3, 1, 1, 1, ad,
+                         acc[0] if stats else None, acc[1] if stats else None, 256 if stats else 0, e * 10000)
+                try:
+                    run()
+                except IsicHipError as err:
+                    print(f"{name} {mode:13s} exp {e}: {err}")
+                    continue
+                torch.cuda.synchronize()
+                st = acc.sum(dim=1).clone()
+                if ref is None:
+                    ref = (out.clone(), st)
+                    same = "ref"
+                else:
+                    same = "bit-equal" if torch.equal(out, ref[0]) and torch.equal(st, ref[1]) else \
+                        f"DIFFERS max {float((out.float() - ref[0].float()).abs().max()):.3e}"
+                acc.zero_()
+                t = timeit(run, a.iters)
+                print(f"{name} {mode:13s} exp {e}: {t:7.4f} ms  {gf / t:7.0f} TF/s  {same}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
