@@ -580,26 +580,18 @@ int isic_conv_halo_launch(const uint16_t* in, const uint16_t* w, uint16_t* out, 
   const int grid = a.groups * a.nslices;
   const int lds2 = lds + WSTAGE;                             // KPB = 2: a fourth weight stage
   const bool kpb2_ok = Cin % 128 == 0 && lds2 <= 160 * 1024;
-  if (experiment && !(relu_mask || yraw)) {                  // A/B experiments (include/isic_hip_test.h): 1 = PRIO, 2 = KPB 2, 3 = both
-    if ((experiment & 2) && !kpb2_ok) return ISIC_ERR_UNSUPPORTED;
-    if (stat_sum && addend) return ISIC_ERR_UNSUPPORTED;
-    if (stat_sum) {
-      if (experiment == 1) return launch_halo<1, false, 1, 1>(a, grid, lds, stream);
-      if (experiment == 2) return launch_halo<1, false, 2, 0>(a, grid, lds2, stream);
-      if (experiment == 3) return launch_halo<1, false, 2, 1>(a, grid, lds2, stream);
-    } else if (!addend) {
-      if (experiment == 1) return launch_halo<0, false, 1, 1>(a, grid, lds, stream);
-      if (experiment == 2) return launch_halo<0, false, 2, 0>(a, grid, lds2, stream);
-      if (experiment == 3) return launch_halo<0, false, 2, 1>(a, grid, lds2, stream);
-    }
-    return ISIC_ERR_UNSUPPORTED;
-  }
+  // shipped: one barrier per two K-tiles + priority for the multiplying waves wherever the fourth weight stage fits
+  // (tools/halo_ab.py, interleaved A/B at 2048 images: l2 +1 %, l3 +2..3.5 %, l4 +3..4 %); experiment 1 = the round-2/3 loop
+  const bool two = kpb2_ok && experiment != 1;
+  if (two) lds = lds2;
+#define HALO_LAUNCH(S, A) (two ? launch_halo<S, A, 2, 1>(a, grid, lds, stream) : launch_halo<S, A, 1, 0>(a, grid, lds, stream))
   if (relu_mask || yraw) {                                 // data gradient feeding a BatchNorm backward (STATS 2)
     if (!relu_mask || !yraw || !stat_sum || !stat_sumsq) return ISIC_ERR_BAD_ARG;
-    return addend ? launch_halo<2, true, 1, 0>(a, grid, lds, stream) : launch_halo<2, false, 1, 0>(a, grid, lds, stream);
+    return addend ? HALO_LAUNCH(2, true) : HALO_LAUNCH(2, false);
   }
   if (stat_sum && addend) return ISIC_ERR_UNSUPPORTED;
-  if (stat_sum) return launch_halo<1, false, 1, 0>(a, grid, lds, stream);
-  if (addend) return launch_halo<0, true, 1, 0>(a, grid, lds, stream);
-  return launch_halo<0, false, 1, 0>(a, grid, lds, stream);
+  if (stat_sum) return HALO_LAUNCH(1, false);
+  if (addend) return HALO_LAUNCH(0, true);
+  return HALO_LAUNCH(0, false);
+#undef HALO_LAUNCH
 }

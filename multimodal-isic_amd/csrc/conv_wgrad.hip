@@ -360,7 +360,7 @@ int conv2d_wgrad_dispatch(const uint16_t* x, const uint16_t* dy, float* dw, int 
     const size_t need = isic_wgrad_c128_workspace_bytes(N, Hin, Win, Cin, Cout);
     if (need != 0) {
       if (workspace_bytes < need) return ISIC_ERR_WORKSPACE;
-      const int rc = isic_wgrad_c128_launch(x, dy, dw, N, Hin, Win, Cin, Cout, workspace, kWgradC128XcdGroup ^ (variant & 1),
+      const int rc = isic_wgrad_c128_launch(x, dy, dw, N, Hin, Win, Cin, Cout, workspace, (kWgradC128XcdGroup ^ (variant & 1)) | (variant & 14),
                                             as_stream(stream));
       return rc != ISIC_OK ? rc : isic_launch_status();
     }

@@ -56,6 +56,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {   /
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// ABL (test builds only, include/isic_hip_test.h): bit 0 = no MFMAs, bit 1 = no fragment reads, bit 2 = no DMA -- where a tile's time goes
+template <int ABL>
 __global__ __launch_bounds__(768) void wgrad_c128_kernel(WC128Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(768) void wgrad_c128_kernel(WC128Args a) {
           src = zeros + (unsigned)(lane * 16);
           dst = 0;
         }
-        glds16(reinterpret_cast<const void*>(src), real ? dst : lds0 + SCR);
+        if (!(ABL & 4)) glds16(reinterpret_cast<const void*>(src), real ? dst : lds0 + SCR);
       }
     };
     issue_tile(ahead, 0, true);
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(768) void wgrad_c128_kernel(WC128Args a) {
     for (int c2 = 0; c2 < 2; ++c2) yb[c2] = st + yaddr[c2];
     auto read_frag = [&](unsigned base_lo, unsigned base_hi, int off) -> bf16x8 {
       s16x8_t t;
+      if (ABL & 2) { t.lo = (s16x4){(short)base_lo, (short)off, 1, 2}; t.hi = t.lo; return __builtin_bit_cast(bf16x8, t); }
       t.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(size_t)(base_lo + (unsigned)off));
       t.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(size_t)(base_hi + (unsigned)off));
       return __builtin_bit_cast(bf16x8, t);
@@ -254,7 +257,8 @@ __global__ __launch_bounds__(768) void wgrad_c128_kernel(WC128Args a) {
         for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
           for (int c2 = 0; c2 < 2; ++c2)
-            acc[kh * 3 + kw][c2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[pr][kw], yf[s][c2], acc[kh * 3 + kw][c2], 0, 0, 0);
+            if (ABL & 1) { acc[kh * 3 + kw][c2][0] += __builtin_bit_cast(float, (int)(short)xf[pr][kw][0] + (int)(short)yf[s][c2][1]); }
+            else acc[kh * 3 + kw][c2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[pr][kw], yf[s][c2], acc[kh * 3 + kw][c2], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -335,13 +339,20 @@ int isic_wgrad_c128_launch(const uint16_t* x, const uint16_t* dy, float* dw, int
   a.tiles_per_block = p.tiles_per_block; a.blocks_per_slice = p.blocks_per_pair;
   a.pairs = p.pairs; a.xcd_group = xcd_group;
   a.Cx = Cin; a.Cy = Cout; a.co_slices = Cout / 32; a.pack = p.pack; a.slot_shift = p.slot_shift; a.Wv = p.Wv;
-  static IsicPerDeviceOnce once;              // hipFuncSetAttribute is per device (one flag set per template instance)
-  if (isic_once_per_device(once, [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_c128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  LDS_ALL);
+  const int abl = (xcd_group >> 1) & 7;
+  a.xcd_group = xcd_group & 1;
+  const void* fns[8] = {(const void*)wgrad_c128_kernel<0>, (const void*)wgrad_c128_kernel<1>, (const void*)wgrad_c128_kernel<2>,
+                        (const void*)wgrad_c128_kernel<3>, (const void*)wgrad_c128_kernel<4>, (const void*)wgrad_c128_kernel<5>,
+                        (const void*)wgrad_c128_kernel<6>, (const void*)wgrad_c128_kernel<7>};
+  static IsicPerDeviceOnce once;              // hipFuncSetAttribute is per device
+  if (isic_once_per_device(once, [&] {
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALL);
+        return e;
       }) != hipSuccess)
     return ISIC_ERR_LAUNCH;
-  hipLaunchKernelGGL(wgrad_c128_kernel, dim3(p.pairs * p.blocks_per_pair), dim3(768), LDS_ALL, stream, a);
+  void* kargs[] = {&a};
+  if (hipLaunchKernel(fns[abl], dim3(p.pairs * p.blocks_per_pair), dim3(768), kargs, LDS_ALL, stream) != hipSuccess) return ISIC_ERR_LAUNCH;
   hipLaunchKernelGGL(wgrad_c128_reduce_kernel, dim3(p.pairs * (SLICE_ELEMS / 64)), dim3(256), 0, stream, a.partial, dw,
                      p.blocks_per_pair, a.co_slices, Cin);
   return ISIC_OK;

@@ -471,6 +471,10 @@ __global__ __launch_bounds__(256) void csr_batch_assemble_kernel(
 
 }  // namespace
 
+bool isic_knn_gram_supported(int D, int k, int max_nodes);
+int isic_knn_gram_launch(const float* x, const int64_t* offsets, int G, int D, int k, int64_t* nn_idx, float* nn_dist,
+                         hipStream_t stream);
+
 extern "C" {
 
 int isic_knn_graph(const float* x, const int64_t* offsets, int G, int D, int k, int max_nodes, int64_t total_nodes,
@@ -478,6 +482,11 @@ int isic_knn_graph(const float* x, const int64_t* offsets, int G, int D, int k, 
   ISIC_CHECK_ARG(G >= 0 && D > 0 && k > 0 && max_nodes >= 0 && total_nodes >= 0);
   if (G == 0 || total_nodes == 0 || max_nodes == 0) return ISIC_OK;
   ISIC_CHECK_ARG(x && offsets && nn_idx && workspace_sqnorm);
+  // graphs of <= 208 nodes: the whole Gram matrix per workgroup, top-k out of the accumulators (knn_gram.hip)
+  if (isic_knn_gram_supported(D, k, max_nodes)) {
+    const int rc = isic_knn_gram_launch(x, offsets, G, D, k, nn_idx, nn_dist, as_stream(stream));
+    return rc != ISIC_OK ? rc : isic_launch_status();
+  }
   const int npad = ((max_nodes + 63) / 64) * 64;
   const size_t lds = (size_t)16 * npad * sizeof(float);
   if (lds > 150 * 1024) return ISIC_ERR_UNSUPPORTED;   // > ~2400 nodes per graph

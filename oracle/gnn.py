@@ -301,7 +301,9 @@ def graphmil_forward(p, cfg, x, edge_index=None, edge_weight=None, drop=None):
 
     ``drop`` = dict(seed, stream_base) enables counter-based dropout in train
     mode: GNN layer i uses stream ``stream_base + i`` with ``gnn_dropout``; the
-    classifier uses ``stream_base + 64`` with ``pool_dropout``.
+    classifier uses ``stream_base + 64`` with ``pool_dropout``.  Optional ``node_offset`` / ``graph_index``: the graph is
+    graph ``graph_index`` of a batch and its first node is row ``node_offset`` of the batched node tensor -- its dropout
+    words are then those of its rows in the batched tensors (node features [sum N, F], classifier hidden [G, Dc]).
     """
     c = dict(DEFAULT_CFG, **cfg)
     t = c["gnn_type"]
@@ -349,7 +351,8 @@ def graphmil_forward(p, cfg, x, edge_index=None, edge_weight=None, drop=None):
             h = F.layer_norm(h, (h.shape[1],), p[f"layer_norms.{i}.weight"], p[f"layer_norms.{i}.bias"])
         h = F.relu(h)
         if drop is not None:
-            h = _mil.dropout(h, c["gnn_dropout"], drop["seed"], drop["stream_base"] + i)
+            h = _mil.dropout(h, c["gnn_dropout"], drop["seed"], drop["stream_base"] + i,
+                             elem_offset=int(drop.get("node_offset", 0)) * h.shape[1])
         if c["use_residual"] and h_prev.shape == h.shape:
             h = h + h_prev
         hs.append(h)
@@ -363,7 +366,8 @@ def graphmil_forward(p, cfg, x, edge_index=None, edge_weight=None, drop=None):
     att = torch.cat(atts, dim=1)                       # 05:213
     u = F.relu(F.linear(z, p["classifier.0.weight"], p["classifier.0.bias"]))   # light head, 05:133-139
     if drop is not None:
-        u = _mil.dropout(u, c["pool_dropout"], drop["seed"], drop["stream_base"] + 64)
+        u = _mil.dropout(u, c["pool_dropout"], drop["seed"], drop["stream_base"] + 64,
+                         elem_offset=int(drop.get("graph_index", 0)) * u.shape[0])
     logits = F.linear(u, p["classifier.3.weight"], p["classifier.3.bias"])
     return {"probs": torch.softmax(logits, dim=0), "att": att, "hs": hs, "z": z, "logits": logits}
 

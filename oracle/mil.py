@@ -19,11 +19,13 @@ import torch.nn.functional as F
 from . import philox
 
 
-def dropout(x, p, seed, stream, training=True):
-    """Counter-based dropout (definition in ``oracle/philox.py``)."""
+def dropout(x, p, seed, stream, training=True, elem_offset=0):
+    """Counter-based dropout (definition in ``oracle/philox.py``).  ``elem_offset``: index of ``x.flat[0]`` in the stream
+    (a bag / graph taken out of a batch keeps the words of its position in the batched tensor)."""
     if (not training) or p <= 0.0:
         return x
-    keep = torch.from_numpy(philox.dropout_keep(x.numel(), p, seed, stream)).view(x.shape)
+    n = x.numel()
+    keep = torch.from_numpy(philox.dropout_keep(elem_offset + n, p, seed, stream)[elem_offset:elem_offset + n].copy()).view(x.shape)
     scale = torch.tensor(float(philox.dropout_scale(p)), dtype=x.dtype)
     return torch.where(keep, x * scale, torch.zeros((), dtype=x.dtype))
 

@@ -193,6 +193,10 @@ def test_conv_halo_kernel(case):
                                     f"max {float((a - b).abs().max()):.3e}"
         # summation order only: the two kernels must agree EXACTLY on the vast majority of outputs
         assert float((got != ref).float().mean()) < 0.02
+        # the shipped K loop (one barrier per two K-tiles, four weight stages, where Cin % 128 == 0) and the round-3 loop (one
+        # barrier per K-tile, three stages: ten-thousands digit 1) add the same products in the same order: bit-equal
+        old, oacc = run(10200, addend, stats)
+        assert torch.equal(got, old) and torch.equal(gacc, oacc), f"two-K-tile loop vs one-K-tile loop {case}"
         if stats:
             o = got.float().reshape(-1, Co).double()
             assert_close(gacc[0].cpu(), o.sum(0).cpu(), rtol=1e-5, atol=1e-3, what="fused sum")
