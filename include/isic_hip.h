@@ -408,6 +408,18 @@ int isic_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dw, int
  * dgrad copy [I][Kh][Kw][O] with both taps flipped (either may be NULL). */
 int isic_conv_weight_prep_bf16(const float* w_krsc, uint16_t* w_fwd, uint16_t* w_dgrad, int O, int I, int Kh, int Kw,
                                void* stream);
+/* isic_conv2d_igemm_bf16 with an addend that is MASKED ON THE FLY: out = conv + (bit ? addend : 0), bit = bit (c & 7) of
+ * addend_mask[(pixel * Cout + c) / 8] -- the 1-bit ReLU mask isic_bn_apply_mask_bf16 writes.  In a ResNet BasicBlock the
+ * data gradient of conv1 is joined with the gradient through the identity, which is d(out) where relu(bn2 + x) was active:
+ * with this entry that gradient is never materialised (one 2-byte write and one 2-byte read per element less than
+ * isic_bn_bwd_apply_mask_bf16(dres = ...) + isic_conv2d_igemm_bf16(addend = dres); the results are bit-identical: a
+ * masked bf16 value is the value or zero).  3x3 / stride 1 / pad 1 layers served by the pixels-staged-once kernels
+ * (64 -> 64; >= 128 channels with Cout % 128 == 0); ..._supported() says so, otherwise ISIC_ERR_UNSUPPORTED. */
+size_t isic_conv2d_maskadd_supported(int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int Kh, int Kw, int up,
+                                    int down, int pad);
+int isic_conv2d_igemm_maskadd_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int Hin, int Win, int Cin,
+                                   int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad,
+                                   const uint16_t* addend, const uint8_t* addend_mask, void* stream);
 /* Data gradient whose output is the gradient g of an activation z = ReLU(BatchNorm(y) [+ residual]) (ResNet BasicBlock:
  * the data gradient of conv2 feeds bn1's backward, that of the next block's conv1 (+ identity addend) feeds bn2's).
  * The epilogue applies the ReLU mask (relu_mask[rows][Cout/8], bit c = channel 8g + c, as written by

@@ -28,8 +28,10 @@ int isic_test_conv2d_igemm_variant_bf16(const uint16_t* in, const uint16_t* w, u
                                         const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots,
                                         int variant, void* stream);
 
-/* isic_conv2d_wgrad_bf16 (same arguments) with `variant`: 0 = shipped; 1 = the all-taps kernel of the >= 128-channel 3x3
- * layers (conv_wgrad_c128.hip) with the block order it does NOT ship with (XCD-grouped co-slice blocks vs pair-major). */
+/* isic_conv2d_wgrad_bf16 (same arguments) with `variant` bits: 0 = shipped; 16 = the 32-output-channel all-taps kernel
+ * (conv_wgrad_c128.hip) where the 64-channel one (conv_wgrad_c128b.hip) ships; on that kernel: 1 = the block order it does
+ * NOT ship with (XCD-grouped co-slice blocks vs pair-major), 2 / 4 / 8 = MFMAs / fragment reads / LDS-DMA compiled out
+ * (timing ablations: the results are garbage). */
 int isic_test_conv2d_wgrad_variant_bf16(const uint16_t* x, const uint16_t* dy, float* dw, int N, int Hin, int Win, int Cin,
                                         int Hout, int Wout, int Cout, int Kh, int Kw, int stride, int pad, void* workspace,
                                         size_t workspace_bytes, int variant, void* stream);

@@ -245,6 +245,7 @@ struct C64PArgs {
   const unsigned short* w;
   unsigned short* out;
   const unsigned short* addend;
+  const unsigned char* addend_mask;     // [pixels][8]: ReLU mask of the addend (added where its bit is set) or NULL
   double* stat_sum;
   double* stat_sumsq;
   int stat_slots;
@@ -253,6 +254,10 @@ struct C64PArgs {
 
 __device__ __attribute__((aligned(256))) unsigned char g_c64_sink[64 * 16];    // stores of out-of-image pixels
 __device__ __attribute__((aligned(256))) unsigned char g_c64_zeros[2048];      // source of out-of-image DMA groups
+__device__ unsigned char g_c64_ones[64] = {255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255,
+                                           255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255,
+                                           255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255,
+                                           255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255};   // "no mask"
 
 #ifdef C64_STAMPS   // per tile: wait start, barrier passed, MFMAs issued, epilogue done (wave 0 of the first 256 blocks, 32 tiles)
 __device__ unsigned long long g_c64p_stamps[256 * 32 * 4];
@@ -405,15 +410,18 @@ __global__ __launch_bounds__(512) void conv3x3_c64p_kernel(C64PArgs a) {
   // is covered by the other wave of the SIMD, which is half a tile away.
   auto epilogue = [&](const Tile& tl) {
     u32x4 ad[4];
+    unsigned amb[4];                           // the addend's ReLU-mask byte of the lane's 8 channels (0xFF: unmasked addend)
     if (ADDEND) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {            // unconditional: exactly 4 loads per tile (see CNT_TOP)
+      for (int i = 0; i < 4; ++i) {            // unconditional: exactly 4 + 4 loads per tile (see CNT_TOP)
         size_t off;
         const int seg = segment(tl, i, off);
         const bool valid = seg == 0 || (seg == 2 && tl.x0 + (i & 1) * 16 + fr < a.W);
         const unsigned char* ap = valid ? reinterpret_cast<const unsigned char*>(a.addend + off) + lane_out
                                         : g_c64_zeros + lane * 16;
         ad[i] = *reinterpret_cast<const u32x4*>(ap);
+        const unsigned char* mp = (valid && a.addend_mask) ? a.addend_mask + ((off * 2 + lane_out) >> 4) : g_c64_ones + lane;
+        amb[i] = *mp;
       }
     }
 #pragma unroll
@@ -426,11 +434,11 @@ __global__ __launch_bounds__(512) void conv3x3_c64p_kernel(C64PArgs a) {
       for (int j = 0; j < 2; ++j) {
         f32x4 c = acc[i][j];
         if (ADDEND) {
-          const unsigned lo = ad[i][2 * j], hi = ad[i][2 * j + 1];
-          c[0] += __uint_as_float(lo << 16);
-          c[1] += __uint_as_float(lo & 0xFFFF0000u);
-          c[2] += __uint_as_float(hi << 16);
-          c[3] += __uint_as_float(hi & 0xFFFF0000u);
+          const unsigned lo = ad[i][2 * j], hi = ad[i][2 * j + 1], bits = amb[i] >> (4 * j);
+          c[0] += (bits & 1u) ? __uint_as_float(lo << 16) : 0.f;
+          c[1] += (bits & 2u) ? __uint_as_float(lo & 0xFFFF0000u) : 0.f;
+          c[2] += (bits & 4u) ? __uint_as_float(hi << 16) : 0.f;
+          c[3] += (bits & 8u) ? __uint_as_float(hi & 0xFFFF0000u) : 0.f;
         }
         const unsigned w0 = pack_bf16x2(c[0], c[1]), w1 = pack_bf16x2(c[2], c[3]);
         v[2 * j] = w0;
@@ -455,7 +463,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64p_kernel(C64PArgs a) {
   // when iteration kk starts.  The waves of channel half 0 run  [DMA kk+2 + MFMAs kk, addend loads kk, stores kk]  per
   // iteration, those of half 1 DEFER the epilogue behind the next barrier --  [addend loads kk-1, stores kk-1,
   // DMA kk+2 + MFMAs kk]  -- so that on every SIMD one wave's epilogue runs under the other wave's MFMAs.
-  constexpr int NEPI = 4 + (ADDEND ? 4 : 0);            // memory operations of one epilogue
+  constexpr int NEPI = 4 + (ADDEND ? 8 : 0);            // memory operations of one epilogue (stores; addend + its mask byte)
   constexpr int CNT_TOP0 = NEPI + P_DMA + NEPI;         // epilogue(kk-2), DMA(kk+1), epilogue(kk-1)
   constexpr int CNT_TOP1 = NEPI + P_DMA;                // epilogue(kk-2), DMA(kk+1)
   if (STATS) lds_barrier();                             // statistics slots zeroed
@@ -544,15 +552,15 @@ int launch_c64p(const C64PArgs& a, int grid, hipStream_t stream) {
 // called by isic_conv2d_igemm_bf16 for Cin = Cout = 64, 3x3, stride 1, pad 1; variant 1 = one tile per block,
 // variant 2 = persistent blocks with register-resident weights
 int isic_conv3x3_c64_launch(int variant, const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int H, int W,
-                            const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots,
-                            hipStream_t stream) {
+                            const uint16_t* addend, const uint8_t* addend_mask, double* stat_sum, double* stat_sumsq,
+                            int stat_slots, hipStream_t stream) {
   const int tiles_y = ceil_div(H, TH), tiles_x = ceil_div(W, TW);
   const int64_t blocks = (int64_t)N * tiles_y * tiles_x;
   if (blocks > 0x7FFFFFFFLL) return ISIC_ERR_UNSUPPORTED;
   if (variant == 2 && !(stat_sum && addend)) {
     const int cus = isic_cu_count();
     C64PArgs a;
-    a.in = in; a.w = w; a.out = out; a.addend = addend;
+    a.in = in; a.w = w; a.out = out; a.addend = addend; a.addend_mask = addend_mask;
     a.stat_sum = stat_sum; a.stat_sumsq = stat_sumsq; a.stat_slots = stat_slots > 0 ? stat_slots : 1;
     a.N = N; a.H = H; a.W = W; a.tiles_y = tiles_y; a.tiles_x = tiles_x;
     a.total_tiles = (int)blocks;
@@ -562,6 +570,7 @@ int isic_conv3x3_c64_launch(int variant, const uint16_t* in, const uint16_t* w, 
     if (addend) return launch_c64p<false, true>(a, grid, stream);
     return launch_c64p<false, false>(a, grid, stream);
   }
+  if (addend_mask) return ISIC_ERR_UNSUPPORTED;            // the persistent kernel above is the one that takes a masked addend
   C64Args a;
   a.in = in; a.w = w; a.out = out; a.addend = addend;
   a.stat_sum = stat_sum; a.stat_sumsq = stat_sumsq; a.stat_slots = stat_slots > 0 ? stat_slots : 1;

@@ -47,6 +47,7 @@ struct HaloArgs {
   const unsigned short* addend;
   double* stat_sum;              // STATS 1: sum of the outputs;  STATS 2: sum of dz
   double* stat_sumsq;            // STATS 1: sum of squares;      STATS 2: sum of dz * y
+  const unsigned char* addend_mask; // STATS 0 + addend: [M][Cout/8] ReLU mask of the ADDEND (it is added where its bit is set) or NULL
   const unsigned char* relu_mask;   // STATS 2: [M][Cout/8], bit c of a byte = ReLU mask of channel 8g + c (isic_bn_apply_mask_bf16)
   const unsigned short* yraw;       // STATS 2: [M][Cout] the pre-BatchNorm activation of the layer whose gradient this is
   int stat_slots;
@@ -102,7 +103,8 @@ __device__ unsigned long long g_halo_stamps[256 * 64 * 4];
 // two stages step S - 1 used and wait for ALL their own DMAs (vmcnt(0): no dummy pieces) in front of barrier S + 1.
 // The next chunk's patch pieces go out at taps 1..6 (not 0..5): a step may hold (chunk c - 1, tap 8) and (chunk c, tap 0),
 // and the buffer of chunk c + 1 is the one chunk c - 1 reads.  Needs Cin % 128 == 0 (an even number of K-tiles per tile).
-template <int STATS, bool ADDEND, int KPB, int PRIO>
+// ABL (test entry only): bit 0 = no MFMAs, bit 1 = no fragment reads, bit 2 = no LDS-DMA -- where a tile's time goes
+template <int STATS, bool ADDEND, int KPB, int PRIO, int ABL = 0>
 __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -161,14 +163,17 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
         if (g >= groups) return;
         const long long pix = (long long)(t_begin + tl) * HM - (a.W + 1) + g * 8 + r8;
         const bool ok = pix >= 0 && pix < a.M;
-        halo_glds16(ok ? (const void*)(a.in + (size_t)pix * a.Cin + cc * 64 + gch * 8) : (const void*)zp,
-                    lds0 + (unsigned)(buf * PB + g * 1024));
+        if (!(ABL & 4))
+          halo_glds16(ok ? (const void*)(a.in + (size_t)pix * a.Cin + cc * 64 + gch * 8) : (const void*)zp,
+                      lds0 + (unsigned)(buf * PB + g * 1024));
       };
       auto weights2 = [&](int tap, int cc, int stage) {
         const unsigned short* s0 = wrow + (size_t)tap * a.Cin + cc * 64;
         const unsigned dst = lds0 + off_w + stage * WSTAGE + sw * 2048;
-        halo_glds16((const void*)s0, dst);
-        halo_glds16((const void*)(s0 + (size_t)16 * 9 * a.Cin), dst + 1024);
+        if (!(ABL & 4)) {
+          halo_glds16((const void*)s0, dst);
+          halo_glds16((const void*)(s0 + (size_t)16 * 9 * a.Cin), dst + 1024);
+        }
       };
 #pragma unroll
       for (int j = 0; j < MAX_PPW; ++j) piece2(j, 0, 0, 0);
@@ -290,14 +295,23 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
             bf16x8 af[4], bfr[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              af[i] = *reinterpret_cast<const bf16x8*>(smem + (aoff[i] ^ (unsigned)(ks << 6)));
-              bfr[i] = *reinterpret_cast<const bf16x8*>(wst + ((boff0 ^ (unsigned)(ks << 6)) + i * 2048));
+              if (ABL & 2) {
+                const unsigned u = aoff[i] + ks, v = boff0 + i;
+                af[i] = __builtin_bit_cast(bf16x8, (u32x4){u, u, u, u});
+                bfr[i] = __builtin_bit_cast(bf16x8, (u32x4){v, v, v, v});
+                asm volatile("" : "+v"(af[i]), "+v"(bfr[i]));
+              } else {
+                af[i] = *reinterpret_cast<const bf16x8*>(smem + (aoff[i] ^ (unsigned)(ks << 6)));
+                bfr[i] = *reinterpret_cast<const bf16x8*>(wst + ((boff0 ^ (unsigned)(ks << 6)) + i * 2048));
+              }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-              for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+              for (int j = 0; j < 4; ++j) {
+                if (ABL & 1) { if (j == 0) asm volatile("" :: "v"(af[i]), "v"(bfr[i])); }
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+              }
           }
           ++tap;
           if (++kw == 3) { kw = 0; ++kh; }
@@ -435,13 +449,17 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
       continue;
     }
     u32x4 ad[4][2];
+    unsigned amb[4][2];              // the addend's ReLU-mask byte (8 channels); 0xFF when the addend comes unmasked
     if (ADDEND) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + i * 16 + fr;
         const unsigned off = (unsigned)(m < a.M ? m : 0) * (unsigned)a.Cout + chan;     // M * Cout < 2^31 (host check)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) ad[i][t] = *reinterpret_cast<const u32x4*>(a.addend + off + t * 32);
+        for (int t = 0; t < 2; ++t) {
+          ad[i][t] = *reinterpret_cast<const u32x4*>(a.addend + off + t * 32);
+          amb[i][t] = a.addend_mask ? (unsigned)a.addend_mask[(off + t * 32) >> 3] : 0xFFu;
+        }
       }
     }
     float s8[2][8], q8[2][8];
@@ -464,11 +482,11 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
         for (int h = 0; h < 2; ++h) {
           f32x4 c = acc[i][2 * t + h];
           if (ADDEND) {
-            const unsigned lo = ad[i][t][2 * h], hi = ad[i][t][2 * h + 1];
-            c[0] += __uint_as_float(lo << 16);
-            c[1] += __uint_as_float(lo & 0xFFFF0000u);
-            c[2] += __uint_as_float(hi << 16);
-            c[3] += __uint_as_float(hi & 0xFFFF0000u);
+            const unsigned lo = ad[i][t][2 * h], hi = ad[i][t][2 * h + 1], bits = amb[i][t] >> (4 * h);
+            c[0] += (bits & 1u) ? __uint_as_float(lo << 16) : 0.f;
+            c[1] += (bits & 2u) ? __uint_as_float(lo & 0xFFFF0000u) : 0.f;
+            c[2] += (bits & 4u) ? __uint_as_float(hi << 16) : 0.f;
+            c[3] += (bits & 8u) ? __uint_as_float(hi & 0xFFFF0000u) : 0.f;
           }
           const unsigned w0 = halo_pack2(c[0], c[1]), w1 = halo_pack2(c[2], c[3]);
           v[2 * h] = w0;
@@ -535,15 +553,15 @@ __global__ __launch_bounds__(1024) void conv_halo_kernel(HaloArgs a) {
   }
 }
 
-template <int STATS, bool ADDEND, int KPB, int PRIO>
+template <int STATS, bool ADDEND, int KPB, int PRIO, int ABL = 0>
 int launch_halo(const HaloArgs& a, int grid, int lds, hipStream_t stream) {
   static IsicPerDeviceOnce once;              // hipFuncSetAttribute is per device (one flag set per template instance)
   if (isic_once_per_device(once, [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<STATS, ADDEND, KPB, PRIO>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<STATS, ADDEND, KPB, PRIO, ABL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       }) != hipSuccess)
     return ISIC_ERR_LAUNCH;
-  hipLaunchKernelGGL((conv_halo_kernel<STATS, ADDEND, KPB, PRIO>), dim3(grid), dim3(1024), lds, stream, a);
+  hipLaunchKernelGGL((conv_halo_kernel<STATS, ADDEND, KPB, PRIO, ABL>), dim3(grid), dim3(1024), lds, stream, a);
   return ISIC_OK;
 }
 
@@ -557,14 +575,15 @@ bool isic_conv_halo_supported(int N, int H, int W, int Cin, int Cout) {
 }
 
 int isic_conv_halo_launch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int H, int W, int Cin, int Cout,
-                          const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots,
-                          const uint8_t* relu_mask, const uint16_t* yraw, int experiment, hipStream_t stream) {
+                          const uint16_t* addend, const uint8_t* addend_mask, double* stat_sum, double* stat_sumsq,
+                          int stat_slots, const uint8_t* relu_mask, const uint16_t* yraw, int experiment, hipStream_t stream) {
   if (!isic_conv_halo_supported(N, H, W, Cin, Cout)) return ISIC_ERR_UNSUPPORTED;
   const int cus = isic_cu_count();
   HaloArgs a;
-  a.in = in; a.w = w; a.out = out; a.addend = addend;
+  a.in = in; a.w = w; a.out = out; a.addend = addend; a.addend_mask = addend_mask;
   a.stat_sum = stat_sum; a.stat_sumsq = stat_sumsq; a.stat_slots = stat_slots > 0 ? stat_slots : 1;
   a.relu_mask = relu_mask; a.yraw = yraw;
+  if (addend_mask && (!addend || relu_mask || yraw || stat_sum)) return ISIC_ERR_UNSUPPORTED;
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.M = N * H * W;
   a.mtiles = ceil_div(a.M, HM);
   a.nslices = Cout / HN;
@@ -584,6 +603,19 @@ int isic_conv_halo_launch(const uint16_t* in, const uint16_t* w, uint16_t* out, 
   // (tools/halo_ab.py, interleaved A/B at 2048 images: l2 +1 %, l3 +2..3.5 %, l4 +3..4 %); experiment 1 = the round-2/3 loop
   const bool two = kpb2_ok && experiment != 1;
   if (two) lds = lds2;
+  if (experiment >= 2) {                                   // timing ablations of the shipped loop (results are garbage): ABL = experiment - 1
+    if (!two || relu_mask || yraw || stat_sum || addend) return ISIC_ERR_UNSUPPORTED;
+    switch (experiment - 1) {
+      case 1: return launch_halo<0, false, 2, 1, 1>(a, grid, lds, stream);
+      case 2: return launch_halo<0, false, 2, 1, 2>(a, grid, lds, stream);
+      case 3: return launch_halo<0, false, 2, 1, 3>(a, grid, lds, stream);
+      case 4: return launch_halo<0, false, 2, 1, 4>(a, grid, lds, stream);
+      case 5: return launch_halo<0, false, 2, 1, 5>(a, grid, lds, stream);
+      case 6: return launch_halo<0, false, 2, 1, 6>(a, grid, lds, stream);
+      case 7: return launch_halo<0, false, 2, 1, 7>(a, grid, lds, stream);
+      default: return ISIC_ERR_UNSUPPORTED;
+    }
+  }
 #define HALO_LAUNCH(S, A) (two ? launch_halo<S, A, 2, 1>(a, grid, lds, stream) : launch_halo<S, A, 1, 0>(a, grid, lds, stream))
   if (relu_mask || yraw) {                                 // data gradient feeding a BatchNorm backward (STATS 2)
     if (!relu_mask || !yraw || !stat_sum || !stat_sumsq) return ISIC_ERR_BAD_ARG;

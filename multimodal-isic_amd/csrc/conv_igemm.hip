@@ -403,13 +403,12 @@ constexpr int kDefaultConvC64 = 2;    // 64 -> 64 3x3 layers: persistent halo ke
 }  // namespace
 
 int isic_conv3x3_c64_launch(int variant, const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int H, int W,
-                            const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots,
-                            hipStream_t stream);
+                            const uint16_t* addend, const uint8_t* addend_mask, double* stat_sum, double* stat_sumsq,
+                            int stat_slots, hipStream_t stream);
 bool isic_conv_halo_supported(int N, int H, int W, int Cin, int Cout);
 int isic_conv_halo_launch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int H, int W, int Cin, int Cout,
-                          const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots, const uint8_t* relu_mask,
-                          const uint16_t* yraw, int experiment,
-                          hipStream_t stream);
+                          const uint16_t* addend, const uint8_t* addend_mask, double* stat_sum, double* stat_sumsq,
+                          int stat_slots, const uint8_t* relu_mask, const uint16_t* yraw, int experiment, hipStream_t stream);
 int isic_conv_pgemm_launch(const isic_conv::ConvArgsN& classes, hipStream_t stream);
 
 namespace {
@@ -437,7 +436,7 @@ inline ConvVariant decode_variant(int v) {
 int conv2d_dispatch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int Hin, int Win, int Cin,
                     int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad,
                     const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots, int variant,
-                    void* stream);
+                    void* stream, const uint8_t* addend_mask = nullptr);
 
 }  // namespace
 
@@ -446,8 +445,9 @@ namespace {
 int conv2d_dispatch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int Hin, int Win, int Cin,
                     int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad,
                     const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots, int variant,
-                    void* stream) {
+                    void* stream, const uint8_t* addend_mask) {
   ISIC_CHECK_ARG(in && w && out);
+  ISIC_CHECK_ARG(!addend_mask || addend);
   ISIC_CHECK_ARG(variant >= 0 && variant < 100000);
   const ConvVariant cv = decode_variant(variant);
   ISIC_CHECK_ARG(cv.mode >= 0 && cv.mode <= 5 && cv.c64 >= 0 && cv.c64 <= 2 && cv.halo >= 0 && cv.halo <= 2 &&
@@ -461,17 +461,18 @@ int conv2d_dispatch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N,
   if ((int64_t)N * Hout * Wout * Cout > 0x7FFFFFFFLL || (int64_t)N * Hin * Win * Cin > 0x7FFFFFFFLL) return ISIC_ERR_UNSUPPORTED;
   const bool same3x3 = Kh == 3 && Kw == 3 && up == 1 && down == 1 && pad == 1 && Hin == Hout && Win == Wout;
   if (Cin == 64 && Cout == 64 && same3x3 && cv.c64 != 0) {
-    const int rc = isic_conv3x3_c64_launch(cv.c64, in, w, out, N, Hin, Win, addend, stat_sum, stat_sumsq, stat_slots,
-                                           as_stream(stream));
+    const int rc = isic_conv3x3_c64_launch(cv.c64, in, w, out, N, Hin, Win, addend, addend_mask, stat_sum, stat_sumsq,
+                                           stat_slots, as_stream(stream));
     return rc != ISIC_OK ? rc : isic_launch_status();
   }
   // >= 128-channel 3x3 layers: every input pixel staged once for all nine taps (conv_halo.hip)
   if (same3x3 && cv.halo != 1 && !(stat_sum && addend) && isic_conv_halo_supported(N, Hin, Win, Cin, Cout) &&
       (cv.halo == 2 || Cin >= 128)) {
-    const int rc = isic_conv_halo_launch(in, w, out, N, Hin, Win, Cin, Cout, addend, stat_sum, stat_sumsq, stat_slots,
-                                         nullptr, nullptr, cv.exp, as_stream(stream));
+    const int rc = isic_conv_halo_launch(in, w, out, N, Hin, Win, Cin, Cout, addend, addend_mask, stat_sum, stat_sumsq,
+                                         stat_slots, nullptr, nullptr, cv.exp, as_stream(stream));
     return rc != ISIC_OK ? rc : isic_launch_status();
   }
+  if (addend_mask) return ISIC_ERR_UNSUPPORTED;            // only the two pixels-staged-once kernels take a masked addend
   ConvArgs a;
   a.in = in; a.w = w; a.out = out; a.addend = addend;
   a.stat_sum = stat_sum; a.stat_sumsq = stat_sumsq; a.stat_slots = stat_slots > 0 ? stat_slots : 1;
@@ -541,6 +542,23 @@ int isic_test_conv2d_igemm_variant_bf16(const uint16_t* in, const uint16_t* w, u
                          stat_sumsq, stat_slots, variant, stream);
 }
 
+size_t isic_conv2d_maskadd_supported(int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int Kh, int Kw, int up,
+                                    int down, int pad) {
+  const bool same3x3 = Kh == 3 && Kw == 3 && up == 1 && down == 1 && pad == 1 && Hin == Hout && Win == Wout;
+  if (!same3x3 || N <= 0) return 0;
+  if (Cin == 64 && Cout == 64) return 1;
+  return Cin >= 128 && isic_conv_halo_supported(N, Hin, Win, Cin, Cout) ? 1 : 0;
+}
+
+int isic_conv2d_igemm_maskadd_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int Hin, int Win, int Cin,
+                                   int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad,
+                                   const uint16_t* addend, const uint8_t* addend_mask, void* stream) {
+  ISIC_CHECK_ARG(addend && addend_mask);
+  if (!isic_conv2d_maskadd_supported(N, Hin, Win, Cin, Hout, Wout, Cout, Kh, Kw, up, down, pad)) return ISIC_ERR_UNSUPPORTED;
+  return conv2d_dispatch(in, w, out, N, Hin, Win, Cin, Hout, Wout, Cout, Kh, Kw, up, down, pad, addend, nullptr, nullptr, 0, 0,
+                         stream, addend_mask);
+}
+
 int isic_conv_weight_prep_bf16(const float* w_krsc, uint16_t* w_fwd, uint16_t* w_dgrad, int O, int I, int Kh, int Kw,
                                void* stream) {
   ISIC_CHECK_ARG(w_krsc && (w_fwd || w_dgrad) && O > 0 && I > 0 && Kh > 0 && Kw > 0);
@@ -569,8 +587,8 @@ int isic_conv2d_dgrad_bnbwd_bf16(const uint16_t* in, const uint16_t* w, uint16_t
                                  double* sum_dzy, int stat_slots, void* stream) {
   ISIC_CHECK_ARG(in && w && out && relu_mask && y_raw && sum_dz && sum_dzy && stat_slots > 0);
   if (!isic_conv2d_dgrad_bnbwd_supported(N, Hin, Win, Cin, Hout, Wout, Cout, Kh, Kw, up, down, pad)) return ISIC_ERR_UNSUPPORTED;
-  const int rc = isic_conv_halo_launch(in, w, out, N, Hin, Win, Cin, Cout, addend, sum_dz, sum_dzy, stat_slots, relu_mask,
-                                       y_raw, 0, as_stream(stream));
+  const int rc = isic_conv_halo_launch(in, w, out, N, Hin, Win, Cin, Cout, addend, nullptr, sum_dz, sum_dzy, stat_slots,
+                                       relu_mask, y_raw, 0, as_stream(stream));
   return rc != ISIC_OK ? rc : isic_launch_status();
 }
 

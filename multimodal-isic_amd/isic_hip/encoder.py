@@ -94,6 +94,9 @@ class ResNet18Encoder(nn.Module):
         # 2048 images: BatchNorm passes -1.0 ms, data gradients +0.75 ms per step -> +0.6 % bags/s, inside the run-to-run
         # noise, while the convolution entry's roofline fraction drops 0.369 -> 0.352: off by default, kept as an option.
         self.fuse_bn_backward = False
+        # the gradient through an identity block's skip is joined from (d out, ReLU mask) inside conv1's data gradient instead
+        # of being written by bn2's backward and read back as an addend (bit-identical; A/B attribute)
+        self.mask_identity_gradient = True
         self._tape_fused = False      # fusion mode of the tape being replayed (recorded at forward time)
         self.grad_ready_hook = None   # callable(list_of_param_names) fired as gradients complete (DDP overlap)
 
@@ -169,16 +172,29 @@ class ResNet18Encoder(nn.Module):
              acc[0] if acc is not None else None, acc[1] if acc is not None else None, STAT_SLOTS)
         return out, acc
 
-    def _conv_dgrad(self, dy, name, in_shape, addend=None):
-        """d_x = dgrad(dy) (+ addend, joined in fp32 inside the kernel's epilogue)."""
+    def _conv_dgrad(self, dy, name, in_shape, addend=None, addend_mask=None):
+        """d_x = dgrad(dy) (+ addend, joined in fp32 inside the kernel's epilogue; with ``addend_mask`` -- a 1-bit ReLU mask --
+        the addend counts only where its bit is set: the gradient through a block's identity, never materialised)."""
         sp = self.specs[name]
         N, H, W, C = in_shape
         _, Ho, Wo, Co = dy.shape
         _, wd = self._weights(name, True)
         dx = _empty(in_shape, dy)
+        if addend_mask is not None:
+            call("isic_conv2d_igemm_maskadd_bf16", dy, wd, dx, N, Ho, Wo, Co, H, W, C, sp.k, sp.k, 1, sp.stride,
+                 sp.k - 1 - sp.pad, addend, addend_mask)
+            return dx
         call("isic_conv2d_igemm_bf16", dy, wd, dx, N, Ho, Wo, Co, H, W, C, sp.k, sp.k, 1, sp.stride, sp.k - 1 - sp.pad,
              addend, None, None, 0)
         return dx
+
+    def _maskadd_ok(self, dy_shape, name, in_shape):
+        """Can the data gradient of this layer take its addend masked on the fly (3x3 stride-1 layers on the
+        pixels-staged-once kernels)?"""
+        sp = self.specs[name]
+        N, H, W, C = in_shape
+        _, Ho, Wo, Co = dy_shape
+        return bool(call("isic_conv2d_maskadd_supported", N, Ho, Wo, Co, H, W, C, sp.k, sp.k, 1, sp.stride, sp.k - 1 - sp.pad))
 
     def _dgrad_bnbwd_ok(self, dy_shape, name, in_shape):
         """Is there a fused kernel for `dgrad(dy) -> ReLU mask -> BatchNorm-backward sums` of this layer?  Decided by
@@ -398,10 +414,15 @@ class ResNet18Encoder(nn.Module):
           * ``prev`` = ``saved`` of the preceding block: the data gradient of conv1 then applies THAT block's output
             mask and returns dz of its bn2 together with the sums (third return value, else None)."""
         x, c1, a1, st1, c2, out, st2, cd, std = saved
+        # identity block: the gradient through the identity is g where relu(bn2 + x) was active -- conv1's data gradient joins
+        # it straight from (g, mask) (isic_conv2d_igemm_maskadd_bf16) and bn2's backward does not write it (round 4)
+        masked_join = (self.mask_identity_gradient and not ds and g_sums is None and len(st2) > 4 and
+                       not (prev is not None and len(prev[6]) > 4 and self._dgrad_bnbwd_ok(c1.shape, f"{pre}.conv1", tuple(x.shape)))
+                       and self._maskadd_ok(c1.shape, f"{pre}.conv1", tuple(x.shape)))
         if g_sums is not None:
             dc2, dres = self._bn_bwd_from_sums(g, c2, st2, f"{pre}.bn2", g_sums), g      # the residual gradient IS dz
         else:
-            dc2, dres = self._bn_bwd(g, c2, out, st2, f"{pre}.bn2", True, True)
+            dc2, dres = self._bn_bwd(g, c2, out, st2, f"{pre}.bn2", True, not masked_join)
         self._conv_wgrad(a1, dc2, f"{pre}.conv2")
         if len(st1) > 4 and self._dgrad_bnbwd_ok(dc2.shape, f"{pre}.conv2", tuple(a1.shape)):
             dz1, sums1 = self._conv_dgrad_bnbwd(dc2, f"{pre}.conv2", tuple(a1.shape), st1[4], c1)
@@ -425,6 +446,8 @@ class ResNet18Encoder(nn.Module):
             names += [f"{pre}.downsample.0.weight", f"{pre}.downsample.1.weight", f"{pre}.downsample.1.bias"]
         elif prev is not None and len(prev[6]) > 4 and self._dgrad_bnbwd_ok(dc1.shape, f"{pre}.conv1", tuple(x.shape)):
             dx, dx_sums = self._conv_dgrad_bnbwd(dc1, f"{pre}.conv1", tuple(x.shape), prev[6][4], prev[4], addend=dres)
+        elif masked_join:
+            dx = self._conv_dgrad(dc1, f"{pre}.conv1", tuple(x.shape), addend=g, addend_mask=st2[4])
         else:
             dx = self._conv_dgrad(dc1, f"{pre}.conv1", tuple(x.shape), addend=dres)   # + identity gradient
         return dx, names, dx_sums

@@ -148,13 +148,43 @@ def test_bare_multi_gpu_launch_starts_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1",
            "--bags-per-step", "2", "--patches", "4", "--image-size", "64", "--no-cpu-baseline", "--sub-steps", "2",
-           "--graphs-per-step", "8", "--images-per-step", "8"]
+           "--graphs-per-step", "8", "--images-per-step", "8", "--teacher-bags-per-step", "8", "--knn-graphs-per-step", "16"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["value"] > 0
     assert line["gnn"]["n_gpus"] == 2 and line["gnn"]["value"] > 0 and line["gnn"]["roofline"]["bound"] == "hbm"
     assert line["vit"]["n_gpus"] == 2 and line["vit"]["value"] > 0 and line["vit"]["roofline"]["bound"] == "hbm"
+    assert line["teacher"]["n_gpus"] == 2 and line["teacher"]["value"] > 0 and line["teacher"]["tuned"]["value"] > 0
+    assert line["knn"]["n_gpus"] == 2 and line["knn"]["value"] > 0 and line["knn"]["roofline"]["bound"] == "mfma"
+    assert "hipGraph" in line["gnn"]["config"]["step_launch"] and "hipGraph" in line["teacher"]["config"]["step_launch"]
+
+
+def test_captured_gnn_step_under_data_parallelism_equals_the_eager_step():
+    """configs[3] under DDP: with world size > 1 the step is TWO hipGraph replays around one eager
+    bucketed all-reduce ([forward + backward] -> GradSync.finish() -> [AdamW + clock.advance()]) instead of ~80 eagerly
+    enqueued launches.  Two ranks on one GPU (gloo collectives): the captured run must not fall back to the eager step and
+    must leave the same parameters as the eager 2-rank run of the same steps (same draws, same dropout words; the AdamW
+    step size of the clock form differs by at most 1 ulp, graphs.py)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    base = [sys.executable, os.path.join(root, "bench.py"), "--config", "gnn", "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "4",
+            "--warmup", "1", "--graphs-per-step", "16", "--no-cpu-baseline"]
+    lines = []
+    for extra in ([], ["--no-graph"]):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+        assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+        lines.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    cap, eager = lines
+    assert cap["n_gpus"] == 2 and "two hipGraph replays" in cap["config"]["step_launch"]
+    assert eager["config"]["step_launch"] == "eager"
+    a, b = cap["config"]["param_l1_after_run"], eager["config"]["param_l1_after_run"]
+    assert abs(a - b) <= 2e-6 * abs(b), (a, b)
+    assert abs(cap["config"]["final_loss"] - eager["config"]["final_loss"]) <= 1e-5 * max(1.0, abs(eager["config"]["final_loss"]))
 
 
 _RCCL_CHILD = r"""

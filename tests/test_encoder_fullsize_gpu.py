@@ -258,6 +258,15 @@ def test_training_step_is_bit_reproducible(images):
     diff = [k for k in g1 if not torch.equal(g1[k], g2[k])]
     assert not diff, f"parameter gradients differ between two identical steps: {diff}"
     assert all(bool(torch.isfinite(v).all()) and float(v.abs().max()) > 0 for v in g1.values())
+    # round 4: the gradient through an identity block's skip joined from (d out, ReLU mask) inside conv1's data gradient
+    # (isic_conv2d_igemm_maskadd_bf16) == written by bn2's backward and read back as an addend: a masked bf16 value is the
+    # value or zero, so EVERY gradient is bit-identical
+    assert enc.mask_identity_gradient
+    enc.mask_identity_gradient = False
+    f3, s3, g3 = run()
+    enc.mask_identity_gradient = True
+    diff = [k for k in g1 if not torch.equal(g1[k], g3[k])]
+    assert not diff, f"masked identity-gradient join changes the gradients: {diff}"
 
 
 def _ref_block(x, P, stride, ds, forced=None):
