@@ -61,10 +61,20 @@ def conv_flops(a):
 
 # forward + data gradient of every non-stem convolution; the second entry is the data gradient with the ReLU mask and
 # the BatchNorm-backward sums in its epilogue (same geometry arguments, same FLOP accounting)
-CONV_ENTRIES = ("isic_conv2d_igemm_bf16", "isic_conv2d_dgrad_bnbwd_bf16")
+CONV_ENTRIES = ("isic_conv2d_igemm_bf16", "isic_conv2d_dgrad_bnbwd_bf16", "isic_conv2d_igemm_maskadd_bf16",
+                "isic_conv2d_dgrad_pair_bf16")
+
+
+def conv_entry_flops(name, a):
+    """Algorithmic FLOPs of one launch of a CONV_ENTRIES entry (``a`` = the recorded call arguments)."""
+    if name == "isic_conv2d_dgrad_pair_bf16":           # (dy, w, dy2, w2, dx, N, Ho, Wo, Co, H, W, C): 3x3 / 2 + 1x1 / 2 data gradients
+        N, Ho, Wo, Co, _H, _W, C = a[5:12]
+        return 2.0 * N * Ho * Wo * Co * C * (9 + 1)       # = the two forward convolutions' counts
+    return conv_flops(a[3:])
 
 KERNEL_CLASSES = (
-    ("conv_fwd_dgrad", ("isic_conv2d_igemm_bf16", "isic_conv2d_dgrad_bnbwd_bf16")),
+    ("conv_fwd_dgrad", ("isic_conv2d_igemm_bf16", "isic_conv2d_dgrad_bnbwd_bf16", "isic_conv2d_igemm_maskadd_bf16",
+                        "isic_conv2d_dgrad_pair_bf16")),
     ("conv_wgrad", ("isic_conv2d_wgrad",)),
     ("stem_conv", ("isic_conv_stem",)),
     ("bn_pool", ("isic_bn_", "isic_maxpool", "isic_avgpool")),
@@ -253,7 +263,7 @@ def run_mil(args, world, rank, dev):
     if rank != 0:
         return None
     conv_ms = sum(ms for _n, _a, ms in conv)
-    conv_fl = sum(conv_flops(a[3:]) for _n, a, _ms in conv)
+    conv_fl = sum(conv_entry_flops(n_, a) for n_, a, _ms in conv)
     n_launch = len(conv)
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     line = base_line("bags/sec (train step) @ 64x224x224 patches/bag", "bags/s", world * B * args.steps / elapsed,
@@ -262,9 +272,10 @@ def run_mil(args, world, rank, dev):
                       "patches_per_bag": K, "patch": f"3x{S}x{S}", "radiomics_dim": R, "parallelism": f"dp{world}",
                       "host_enqueue_ms_per_step": host_s * 1e3 / args.steps, "final_loss": final_loss}
     line["roofline"] = {
-        "bound": "mfma", "kernel": "C-ABI entries isic_conv2d_igemm_bf16 + isic_conv2d_dgrad_bnbwd_bf16 (forward + data "
-                                   "gradient of every non-stem convolution: conv_halo / conv3x3_c64p / conv_pgemm / "
-                                   "conv_igemm kernels; 38 launches per step)",
+        "bound": "mfma", "kernel": "C-ABI entries isic_conv2d_igemm_bf16 + isic_conv2d_igemm_maskadd_bf16 + "
+                                   "isic_conv2d_dgrad_bnbwd_bf16 + isic_conv2d_dgrad_pair_bf16 (forward + data gradient of every "
+                                   "non-stem convolution: conv_halo / conv3x3_c64p / conv_pgemm / conv_igemm kernels; 35 launches "
+                                   "per step -- the 1x1 downsample data gradients ride inside the 3x3 stride-2 ones)",
         "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
         "traffic": pmc_traffic("mil", bags_per_step=B, patches=K, image_size=S),

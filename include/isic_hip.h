@@ -408,6 +408,15 @@ int isic_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dw, int
  * dgrad copy [I][Kh][Kw][O] with both taps flipped (either may be NULL). */
 int isic_conv_weight_prep_bf16(const float* w_krsc, uint16_t* w_fwd, uint16_t* w_dgrad, int O, int I, int Kh, int Kw,
                                void* stream);
+/* Data gradient of a ResNet DOWNSAMPLE block's two stride-2 convolutions in one launch: dx = dgrad3x3/2(dy; w) +
+ * dgrad1x1/2(dy2; w2), both reading [N, Ho, Wo, Co] gradients and writing [N, H, W, C] (H = 2 Ho, pad 1 / pad 0).  The 1x1
+ * convolution's taps land on the even pixels only: its K-tiles are appended to the 3x3 gradient's even-pixel parity class and
+ * accumulate into the same registers -- instead of a kernel that writes three zeros per value (an [N, H, W, C] tensor) and
+ * a second one that reads it back as an addend.  w = isic_conv_weight_prep_bf16's dgrad copy [C][3][3][Co], w2 = the 1x1
+ * layer's [C][Co].  Sum order: the 3x3 taps, then the 1x1 term, in fp32, one rounding (the two-launch form rounds the 1x1
+ * term to bf16 first). */
+int isic_conv2d_dgrad_pair_bf16(const uint16_t* dy, const uint16_t* w, const uint16_t* dy2, const uint16_t* w2, uint16_t* dx,
+                                int N, int Ho, int Wo, int Co, int H, int W, int C, void* stream);
 /* isic_conv2d_igemm_bf16 with an addend that is MASKED ON THE FLY: out = conv + (bit ? addend : 0), bit = bit (c & 7) of
  * addend_mask[(pixel * Cout + c) / 8] -- the 1-bit ReLU mask isic_bn_apply_mask_bf16 writes.  In a ResNet BasicBlock the
  * data gradient of conv1 is joined with the gradient through the identity, which is d(out) where relu(bn2 + x) was active:

@@ -19,7 +19,13 @@ struct ConvArgs {
   // taps of this launch: kh = kh0 + kstep*i (i < nkh), kw = kw0 + kstep*j (j < nkw)
   int kh0, kw0, kstep, nkh, nkw;
   int M;        // N*Hs*Ws
-  int Ktiles;   // nkh*nkw*Cin/64
+  // a SECOND source joined into the same accumulators (round 4: the 1x1 / stride-2 downsample's data gradient inside the
+  // 3x3 / stride-2 data gradient of a ResNet downsample block): K-tiles [Kmain, Ktiles) read `in2` (same geometry and
+  // channel count as `in`) at the pixel of the class's tap (0, 0), with weights w2[Cout][Cin]; NULL / Kmain == Ktiles: none
+  const unsigned short* in2;
+  const unsigned short* w2;
+  int Kmain;    // nkh*nkw*Cin/64
+  int Ktiles;   // Kmain (+ Cin/64 for the class that owns the second source)
   int ctiles;   // Cin/64
   unsigned long long magic_hw, magic_w;   // floor(2^40/d)+1 for d = Hs*Ws and d = Ws (M < 2^24)
 };

@@ -177,20 +177,23 @@ __global__ __launch_bounds__((MODE >= 4 ? 2 : 1) * WAVES_M * WAVES_N * 64, MODE 
     typedef const __attribute__((address_space(1))) void* gbl_ptr;
     const unsigned char* zp = g_zero_page + (tid & 7) * 16;
     auto issue = [&](int kt, unsigned char* stage) {
-      const int tap = kt / a.ctiles, c0 = (kt - tap * a.ctiles) * BK;
+      const bool second = kt >= a.Kmain;                   // the joined second source (conv_args.h): tap (0, 0), own weights
+      const int tap = second ? 0 : kt / a.ctiles, c0 = ((second ? kt - a.Kmain : kt) - tap * a.ctiles) * BK;
       const int ti = tap / a.nkw, tj = tap - ti * a.nkw;
       const int toff = ((dh0 + dstep * ti) * a.Win + (dw0 + dstep * tj)) * a.Cin + c0;          // uniform
-      const int koff = ((a.kh0 + a.kstep * ti) * a.Kw + (a.kw0 + a.kstep * tj)) * a.Cin + c0;     // uniform
+      const int koff = second ? c0 : ((a.kh0 + a.kstep * ti) * a.Kw + (a.kw0 + a.kstep * tj)) * a.Cin + c0;     // uniform
+      const unsigned short* inp = second ? a.in2 : a.in;
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) {
         const bool ok = ((a_vh[i] >> ti) & (a_vw[i] >> tj)) & 1u;
-        const void* src = ok ? (const void*)(a.in + (a_off[i] + toff)) : (const void*)zp;
+        const void* src = ok ? (const void*)(inp + (a_off[i] + toff)) : (const void*)zp;
         __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(stage + (wave * 8 + RPP * i) * 128), 16, 0, 0);
       }
 #pragma unroll
-      for (int i = 0; i < BROWS; ++i)
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(wrow_ptr[i] + koff),
-                                         (lds_ptr)(stage + A_BYTES + (wave * 8 + RPP * i) * 128), 16, 0, 0);
+      for (int i = 0; i < BROWS; ++i) {
+        const unsigned short* wp = second ? a.w2 + (size_t)(n0 + sr + RPP * i) * a.Cin + sc * 8 : wrow_ptr[i];
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(wp + koff), (lds_ptr)(stage + A_BYTES + (wave * 8 + RPP * i) * 128), 16, 0, 0);
+      }
     };
     constexpr int LPT = AROWS + BROWS;        // LDS-DMA instructions per wave per K-tile
     if (MODE >= 4) {
@@ -436,7 +439,8 @@ inline ConvVariant decode_variant(int v) {
 int conv2d_dispatch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int Hin, int Win, int Cin,
                     int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad,
                     const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots, int variant,
-                    void* stream, const uint8_t* addend_mask = nullptr);
+                    void* stream, const uint8_t* addend_mask = nullptr, const uint16_t* in2 = nullptr,
+                    const uint16_t* w2 = nullptr);
 
 }  // namespace
 
@@ -445,9 +449,12 @@ namespace {
 int conv2d_dispatch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int Hin, int Win, int Cin,
                     int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad,
                     const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots, int variant,
-                    void* stream, const uint8_t* addend_mask) {
+                    void* stream, const uint8_t* addend_mask, const uint16_t* in2, const uint16_t* w2) {
   ISIC_CHECK_ARG(in && w && out);
   ISIC_CHECK_ARG(!addend_mask || addend);
+  ISIC_CHECK_ARG((in2 == nullptr) == (w2 == nullptr));
+  // a second source exists for the stride-2 3x3 data gradient only (pad' = 1: its even-pixel class has the single tap (1, 1))
+  if (in2 && !(Kh == 3 && Kw == 3 && up == 1 && down == 2 && pad == 1 && !addend && !stat_sum)) return ISIC_ERR_UNSUPPORTED;
   ISIC_CHECK_ARG(variant >= 0 && variant < 100000);
   const ConvVariant cv = decode_variant(variant);
   ISIC_CHECK_ARG(cv.mode >= 0 && cv.mode <= 5 && cv.c64 >= 0 && cv.c64 <= 2 && cv.halo >= 0 && cv.halo <= 2 &&
@@ -498,7 +505,13 @@ int conv2d_dispatch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N,
       if (a.M >= (1 << 24) || a.Hs * a.Ws >= (1 << 16)) return ISIC_ERR_UNSUPPORTED;   // fastdiv40 domain
       a.magic_hw = ((1ULL << 40) / (unsigned long long)(a.Hs * a.Ws)) + 1;
       a.magic_w = ((1ULL << 40) / (unsigned long long)a.Ws) + 1;
-      a.Ktiles = a.nkh * a.nkw * a.ctiles;
+      a.Kmain = a.nkh * a.nkw * a.ctiles;
+      a.Ktiles = a.Kmain;
+      a.in2 = nullptr; a.w2 = nullptr;
+      if (in2 && a.nkh == 1 && a.nkw == 1 && ph == 0 && pw == 0) {       // the class of the even output pixels: 1x1 / stride-2 taps land here
+        a.in2 = in2; a.w2 = w2;
+        a.Ktiles = a.Kmain + a.ctiles;
+      }
       // a class without any tap still has to write (addend or zeros): Ktiles == 0 is handled by the kernel
       if (a.nkh > 16 || a.nkw > 16) return ISIC_ERR_UNSUPPORTED;   // per-row tap validity lives in 2 x 16+ bits
       all.c[all.n++] = a;
@@ -515,6 +528,7 @@ int conv2d_dispatch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N,
   {
     int rc;
     const int mode = cv.mode;
+    if (in2 && mode < 4) return ISIC_ERR_UNSUPPORTED;      // the second source is read by the LDS-DMA staging waves only
     if (Cout % 128 != 0) rc = launch_conv_mode<256, 64, 4, 1>(mode == 5 ? 4 : mode, all, s);
     else if (mode == 5) rc = launch_conv<256, 128, 4, 2, 5>(all, s);        // 8 MFMA + 8 staging waves, three stages
     else rc = launch_conv_mode<128, 128, 2, 2>(mode, all, s);
@@ -540,6 +554,13 @@ int isic_test_conv2d_igemm_variant_bf16(const uint16_t* in, const uint16_t* w, u
                                         int variant, void* stream) {
   return conv2d_dispatch(in, w, out, N, Hin, Win, Cin, Hout, Wout, Cout, Kh, Kw, up, down, pad, addend, stat_sum,
                          stat_sumsq, stat_slots, variant, stream);
+}
+
+int isic_conv2d_dgrad_pair_bf16(const uint16_t* dy, const uint16_t* w, const uint16_t* dy2, const uint16_t* w2, uint16_t* dx,
+                                int N, int Ho, int Wo, int Co, int H, int W, int C, void* stream) {
+  ISIC_CHECK_ARG(dy && w && dy2 && w2 && dx);
+  return conv2d_dispatch(dy, w, dx, N, Ho, Wo, Co, H, W, C, 3, 3, 1, 2, 1, nullptr, nullptr, nullptr, 0, 0, stream, nullptr,
+                         dy2, w2);
 }
 
 size_t isic_conv2d_maskadd_supported(int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int Kh, int Kw, int up,

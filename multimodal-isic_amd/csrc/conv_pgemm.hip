@@ -135,23 +135,28 @@ __global__ __launch_bounds__(1024) void conv_pgemm_kernel(PGemmArgs pa) {
       }
     };
     // the six DMAs of K-tile kt of the tile whose row state is loaded; live = false: dummy pieces (constant count)
+    const unsigned short* wrow2 = a.w2 ? a.w2 + (size_t)(n0 + chan0) * a.Cin + gch * 8 : a.w;   // second source: [Cout][Cin]
     auto issue = [&](int kt, int stage, bool live) {
-      const int tap = kt / a.ctiles, c0 = (kt - tap * a.ctiles) * 64;
+      const bool second = kt >= a.Kmain;                   // the joined second source (conv_args.h): tap (0, 0), own weights
+      const int tap = second ? 0 : kt / a.ctiles, c0 = ((second ? kt - a.Kmain : kt) - tap * a.ctiles) * 64;
       const int ti = tap / a.nkw, tj = tap - ti * a.nkw;
       const int toff = ((dh0 + ti) * a.Win + (dw0 + tj)) * a.Cin + c0;
-      const int koff = ((a.kh0 + a.kstep * ti) * a.Kw + (a.kw0 + a.kstep * tj)) * a.Cin + c0;
+      const int koff = second ? c0 : ((a.kh0 + a.kstep * ti) * a.Kw + (a.kw0 + a.kstep * tj)) * a.Cin + c0;
+      const unsigned short* inp = second ? a.in2 : a.in;
+      const unsigned short* wp = second ? wrow2 : wrow;
+      const size_t wstep = second ? (size_t)16 * a.Cin : (size_t)16 * Ktot;
       const unsigned sbase = lds0 + stage * P_STAGE;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const bool ok = live && (((a_vh[i] >> ti) & (a_vw[i] >> tj)) & 1u);
-        const void* src = ok ? (const void*)(a.in + (a_off[i] + toff)) : (const void*)zp;
+        const void* src = ok ? (const void*)(inp + (a_off[i] + toff)) : (const void*)zp;
         pg_glds16(src, live ? sbase + (unsigned)((sw + 8 * i) * 1024) : scr);
       }
       if (PN == 128) {
-        pg_glds16(live ? (const void*)(wrow + koff) : (const void*)zp, live ? sbase + P_A + sw * 2048 : scr);
-        pg_glds16(live ? (const void*)(wrow + koff + (size_t)16 * Ktot) : (const void*)zp, live ? sbase + P_A + sw * 2048 + 1024 : scr);
+        pg_glds16(live ? (const void*)(wp + koff) : (const void*)zp, live ? sbase + P_A + sw * 2048 : scr);
+        pg_glds16(live ? (const void*)(wp + koff + wstep) : (const void*)zp, live ? sbase + P_A + sw * 2048 + 1024 : scr);
       } else {
-        pg_glds16(live ? (const void*)(wrow + koff) : (const void*)zp, live ? sbase + P_A + sw * 1024 : scr);
+        pg_glds16(live ? (const void*)(wp + koff) : (const void*)zp, live ? sbase + P_A + sw * 1024 : scr);
       }
     };
 

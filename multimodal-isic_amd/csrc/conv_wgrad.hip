@@ -290,7 +290,7 @@ int isic_wgrad_c128_launch(const uint16_t* x, const uint16_t* dy, float* dw, int
 // ... 64 output channels per block (conv_wgrad_c128b.hip): Cin % 128 == 0, Cout % 64 == 0
 size_t isic_wgrad_c128b_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int isic_wgrad_c128b_launch(const uint16_t* x, const uint16_t* dy, float* dw, int N, int H, int W, int Cin, int Cout,
-                            void* workspace, hipStream_t stream);
+                            void* workspace, int ablation, hipStream_t stream);
 
 namespace {
 // the all-taps kernels are always used for the shapes they cover (no environment switches, no global state)
@@ -368,7 +368,7 @@ int conv2d_wgrad_dispatch(const uint16_t* x, const uint16_t* dy, float* dw, int 
     const size_t need = isic_wgrad_c128b_workspace_bytes(N, Hin, Win, Cin, Cout);
     if (need != 0) {
       if (workspace_bytes < need) return ISIC_ERR_WORKSPACE;
-      const int rc = isic_wgrad_c128b_launch(x, dy, dw, N, Hin, Win, Cin, Cout, workspace, as_stream(stream));
+      const int rc = isic_wgrad_c128b_launch(x, dy, dw, N, Hin, Win, Cin, Cout, workspace, ((variant >> 1) & 7) | ((variant >> 5) & 3) << 4, as_stream(stream));
       return rc != ISIC_OK ? rc : isic_launch_status();
     }
   }

@@ -53,6 +53,10 @@ __device__ __forceinline__ void glds16b(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// ABL (test entry only): bit 0 = no MFMAs, bit 1 = no fragment reads, bit 2 = no LDS-DMA -- where a tile's time goes
+// DPAT: when a tile's nine LDS-DMA groups (of the NEXT tile) go out: 0 = one per MFMA group (groups 0-8 of 12), 1 = two per
+// group (groups 0-4), 2 = all nine in front of the first group
+template <int ABL, int DPAT = 0>
 __global__ __launch_bounds__(512) void wgrad_c128b_kernel(WC128BArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(512) void wgrad_c128b_kernel(WC128BArgs a) {
       src = zeros + (unsigned)(lane * 16);
       dst = 0;
     }
-    glds16b(reinterpret_cast<const void*>(src), real ? dst : lds0 + SCR);
+    if (!(ABL & 4)) glds16b(reinterpret_cast<const void*>(src), real ? dst : lds0 + SCR);
   };
 
   // ---------------------------------------------------------------- fragments: wave c = input channels 16c .. 16c+16
@@ -169,6 +173,7 @@ __global__ __launch_bounds__(512) void wgrad_c128b_kernel(WC128BArgs a) {
     const int nstage = (kk + 1) & 1;
     auto read_frag = [&](unsigned base_lo, unsigned base_hi, int off) -> bf16x8 {
       s16x8_t t;
+      if (ABL & 2) { t.lo = (s16x4){(short)base_lo, (short)off, 1, 2}; t.hi = t.lo; return __builtin_bit_cast(bf16x8, t); }
       t.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(size_t)(base_lo + (unsigned)off));
       t.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(size_t)(base_hi + (unsigned)off));
       return __builtin_bit_cast(bf16x8, t);
@@ -191,12 +196,20 @@ __global__ __launch_bounds__(512) void wgrad_c128b_kernel(WC128BArgs a) {
       for (int kh = 0; kh < 3; ++kh) {
         // the tile's nine DMA groups of the NEXT tile go out between the MFMA groups: 12 slots per tile, 9 used
         const int slot = s * 3 + kh;
-        if (slot < NDMA) dma_one(slot, ahead, nstage, more);
+        if (DPAT == 0) { if (slot < NDMA) dma_one(slot, ahead, nstage, more); }
+        else if (DPAT == 1) {
+          if (2 * slot < NDMA) dma_one(2 * slot, ahead, nstage, more);
+          if (2 * slot + 1 < NDMA) dma_one(2 * slot + 1, ahead, nstage, more);
+        } else if (slot == 0) {
+#pragma unroll
+          for (int j = 0; j < NDMA; ++j) dma_one(j, ahead, nstage, more);
+        }
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
           for (int c2 = 0; c2 < 4; ++c2)
-            acc[kh * 3 + kw][c2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[s + kh][kw], yf[c2], acc[kh * 3 + kw][c2], 0, 0, 0);
+            if (ABL & 1) acc[kh * 3 + kw][c2][0] += __builtin_bit_cast(float, (int)(short)xf[s + kh][kw][0] + (int)(short)yf[c2][1]);
+            else acc[kh * 3 + kw][c2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[s + kh][kw], yf[c2], acc[kh * 3 + kw][c2], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);      // a DMA's address arithmetic and the fragment reads stay in their own slot
       }
     }
@@ -268,7 +281,7 @@ size_t isic_wgrad_c128b_workspace_bytes(int N, int H, int W, int Cin, int Cout) 
 
 // called by isic_conv2d_wgrad_bf16 for 3x3, stride 1, pad 1, Cin % 128 == 0, Cout % 64 == 0
 int isic_wgrad_c128b_launch(const uint16_t* x, const uint16_t* dy, float* dw, int N, int H, int W, int Cin, int Cout,
-                            void* workspace, hipStream_t stream) {
+                            void* workspace, int ablation, hipStream_t stream) {
   WC128BPlan p;
   if (!wc128b_plan(N, H, W, Cin, Cout, p)) return ISIC_ERR_UNSUPPORTED;
   WC128BArgs a;
@@ -277,13 +290,20 @@ int isic_wgrad_c128b_launch(const uint16_t* x, const uint16_t* dy, float* dw, in
   a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x; a.total_tiles = p.total_tiles;
   a.tiles_per_block = p.tiles_per_block; a.blocks_per_pair = p.blocks_per_pair;
   a.Cx = Cin; a.Cy = Cout; a.co_slices = Cout / 64; a.pack = p.pack; a.slot_shift = p.slot_shift; a.Wv = p.Wv;
+  const void* fns[10] = {(const void*)wgrad_c128b_kernel<0>, (const void*)wgrad_c128b_kernel<1>, (const void*)wgrad_c128b_kernel<2>,
+                         (const void*)wgrad_c128b_kernel<3>, (const void*)wgrad_c128b_kernel<4>, (const void*)wgrad_c128b_kernel<5>,
+                         (const void*)wgrad_c128b_kernel<6>, (const void*)wgrad_c128b_kernel<7>,
+                         (const void*)wgrad_c128b_kernel<0, 1>, (const void*)wgrad_c128b_kernel<0, 2>};
   static IsicPerDeviceOnce once;
-  if (isic_once_per_device(once, [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_c128b_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   LDS_ALL);
+  if (isic_once_per_device(once, [&] {
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < 10 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALL);
+        return e;
       }) != hipSuccess)
     return ISIC_ERR_LAUNCH;
-  hipLaunchKernelGGL(wgrad_c128b_kernel, dim3(p.pairs * p.blocks_per_pair), dim3(512), LDS_ALL, stream, a);
+  void* kargs[] = {&a};
+  if (hipLaunchKernel(fns[ablation >= 16 ? 8 + ((ablation >> 4) - 1) % 2 : (ablation & 7)], dim3(p.pairs * p.blocks_per_pair), dim3(512), kargs, LDS_ALL, stream) != hipSuccess)
+    return ISIC_ERR_LAUNCH;
   hipLaunchKernelGGL(wgrad_c128b_reduce_kernel, dim3(p.pairs * (SLICE_ELEMS / 64)), dim3(256), 0, stream, a.partial, dw,
                      p.blocks_per_pair, a.co_slices, Cin);
   return ISIC_OK;

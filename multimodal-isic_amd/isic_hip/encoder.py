@@ -16,7 +16,7 @@ import os
 import torch
 import torch.nn as nn
 
-from .lib import IsicHipError, call
+from .lib import ERR_UNSUPPORTED, IsicHipError, call
 
 LAYERS = ((64, 1), (128, 2), (256, 2), (512, 2))
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
@@ -97,6 +97,8 @@ class ResNet18Encoder(nn.Module):
         # the gradient through an identity block's skip is joined from (d out, ReLU mask) inside conv1's data gradient instead
         # of being written by bn2's backward and read back as an addend (bit-identical; A/B attribute)
         self.mask_identity_gradient = True
+        # downsample blocks: both stride-2 data gradients in one launch (A/B attribute; one bf16 rounding less than two launches)
+        self.pair_downsample_gradient = True
         self._tape_fused = False      # fusion mode of the tape being replayed (recorded at forward time)
         self.grad_ready_hook = None   # callable(list_of_param_names) fired as gradients complete (DDP overlap)
 
@@ -187,6 +189,27 @@ class ResNet18Encoder(nn.Module):
         call("isic_conv2d_igemm_bf16", dy, wd, dx, N, Ho, Wo, Co, H, W, C, sp.k, sp.k, 1, sp.stride, sp.k - 1 - sp.pad,
              addend, None, None, 0)
         return dx
+
+    def _conv_dgrad_pair(self, dy, name, dy2, name2, in_shape):
+        """d_x of a downsample block: dgrad(conv1 3x3 / 2)(dy) + dgrad(downsample 1x1 / 2)(dy2) in ONE launch
+        (isic_conv2d_dgrad_pair_bf16: the 1x1 term accumulates in the even-pixel class of the 3x3 gradient; the two-launch
+        form wrote an input-sized tensor that is three quarters zeros and read it back as an addend)."""
+        sp, sp2 = self.specs[name], self.specs[name2]
+        N, H, W, C = in_shape
+        _, Ho, Wo, Co = dy.shape
+        if self.pair_downsample_gradient and sp.k == 3 and sp.stride == 2 and sp.pad == 1 and sp2.k == 1 and sp2.stride == 2 \
+                and sp2.pad == 0 and tuple(dy2.shape) == tuple(dy.shape):
+            _, wd = self._weights(name, True)
+            _, wd2 = self._weights(name2, True)
+            dx = _empty(in_shape, dy)
+            try:
+                call("isic_conv2d_dgrad_pair_bf16", dy, wd, dy2, wd2, dx, N, Ho, Wo, Co, H, W, C)
+                return dx
+            except IsicHipError as e:
+                if e.code != ERR_UNSUPPORTED:
+                    raise
+        dx2 = self._conv_dgrad(dy2, name2, in_shape)
+        return self._conv_dgrad(dy, name, in_shape, addend=dx2)
 
     def _maskadd_ok(self, dy_shape, name, in_shape):
         """Can the data gradient of this layer take its addend masked on the fly (3x3 stride-1 layers on the
@@ -441,8 +464,7 @@ class ResNet18Encoder(nn.Module):
         if ds:
             dcd, _ = self._bn_bwd(dres, cd, None, std, f"{pre}.downsample.1", False, False)
             self._conv_wgrad(x, dcd, f"{pre}.downsample.0")
-            dx2 = self._conv_dgrad(dcd, f"{pre}.downsample.0", tuple(x.shape))
-            dx = self._conv_dgrad(dc1, f"{pre}.conv1", tuple(x.shape), addend=dx2)
+            dx = self._conv_dgrad_pair(dc1, f"{pre}.conv1", dcd, f"{pre}.downsample.0", tuple(x.shape))
             names += [f"{pre}.downsample.0.weight", f"{pre}.downsample.1.weight", f"{pre}.downsample.1.bias"]
         elif prev is not None and len(prev[6]) > 4 and self._dgrad_bnbwd_ok(dc1.shape, f"{pre}.conv1", tuple(x.shape)):
             dx, dx_sums = self._conv_dgrad_bnbwd(dc1, f"{pre}.conv1", tuple(x.shape), prev[6][4], prev[4], addend=dres)

@@ -246,6 +246,7 @@ def train_milnet_fold(model, train_set, val_set, *, optimizer="adamw", lr=2.2e-4
     for epoch in range(1, epochs + 1):
         model.train()
         order = weighted_sample_indices(tr.labels, gen)
+        step_losses = []                          # device scalars: read back once per epoch (no sync inside the loop)
         for s in range(0, len(order), per_step):
             glob = order[s:s + per_step]
             lo, hi = ddp.shard_range(len(glob), rank, world)
@@ -256,7 +257,9 @@ def train_milnet_fold(model, train_set, val_set, *, optimizer="adamw", lr=2.2e-4
                 img, rad, y = tr.batch(mine)
                 with ops.fused_grad_accumulation():
                     out = model(img, rad)
-                    (model.loss(out, y) * (len(mine) * world / len(glob))).backward()
+                    loss = model.loss(out, y)
+                    step_losses.append(loss.detach())
+                    (loss * (len(mine) * world / len(glob))).backward()
             _sync_step(opt, sync, world)
         ddp.average_buffers(model)               # BatchNorm running statistics are per rank during the epoch
         probs, val_loss = eval_milnet(model, va)
@@ -270,7 +273,8 @@ def train_milnet_fold(model, train_set, val_set, *, optimizer="adamw", lr=2.2e-4
             best["loss"], best["no_improve"], best["state_loss"] = val_loss, 0, snapshot()
         else:
             best["no_improve"] += 1
-        history.append({"epoch": epoch, "val_auc": m["auc"], "val_bacc": bacc, "val_loss": val_loss, "probs": probs})
+        history.append({"epoch": epoch, "val_auc": m["auc"], "val_bacc": bacc, "val_loss": val_loss, "probs": probs,
+                        "train_losses": [float(v) for v in torch.stack(step_losses).cpu()] if step_losses else []})
         if rank == 0 and log:
             log(f"    Epoch {epoch:03d}: Val AUROC: {m['auc']:.4f} | Val BAcc: {bacc:.4f} (best: {best['bacc']:.4f})  | "
                 f"Val Loss: {val_loss:.4f} (best: {best['loss']:.4f} ) | Epochs no improve: {best['no_improve']}/{patience}")

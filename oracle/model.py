@@ -25,7 +25,7 @@ def sub(p, prefix):
 
 
 def milnet_forward(p, image, radiomics, offsets, emulate_bf16=False, layers=resnet.LAYERS, fusion_strategy="concat",
-                   drop=None, mil_dropout=0.0, running=None, training=True):
+                   drop=None, mil_dropout=0.0, running=None, training=True, acc64=False):
     """image[T,3,H,W], radiomics[B,R], offsets[B+1] -> dict like model.MultiModalMILNet.
 
     BatchNorm uses batch statistics (``training=True``; ``running`` = encoder-relative buffer dict updated in place when
@@ -34,7 +34,7 @@ def milnet_forward(p, image, radiomics, offsets, emulate_bf16=False, layers=resn
     image_proj (p .3/.2, streams step*1024 + 0/1), radiomics_mlp (.4/.3, +2/3), fusion_mlp (.4, +8)
     under ``seed``; the MIL head's own site (p = mil_dropout, stream step*1024) under ``seed + 1``."""
     feats = resnet.resnet18_features(sub(p, "encoder"), image, emulate_bf16=emulate_bf16, layers=layers,
-                                     running=running, training=training)
+                                     running=running, training=training, acc64=acc64)
     mdrop = None
     fdrop = None
     if drop is not None:

@@ -97,10 +97,14 @@ def fresh_running(p):
     return out
 
 
-def resnet18_features(p, x, emulate_bf16=False, stats=None, taps=None, layers=LAYERS, running=None, training=True):
+def resnet18_features(p, x, emulate_bf16=False, stats=None, taps=None, layers=LAYERS, running=None, training=True, acc64=False):
     """x[N,3,H,W] fp32 -> features[N,512] fp32.  ``training=True``: batch-statistics BatchNorm (and the running
     estimates in ``running`` are updated when given); ``training=False``: normalise with ``running``.  ``layers``
-    shortens the network for well-conditioned tests (default: the four ResNet-18 stages)."""
+    shortens the network for well-conditioned tests (default: the four ResNet-18 stages).
+    ``acc64``: every convolution (forward, data and weight gradient) accumulates in float64 and is rounded to float32 once --
+    the SAME arithmetic in another summation order.  With ``emulate_bf16`` this is the yardstick for what a different
+    summation order (the MFMA's, say) does to a bf16 pipeline: the float32 values in front of each bf16 rounding move by
+    ~1e-7 relative, a few of the millions of activations / gradients round the other way, and training amplifies that."""
     e = emulate_bf16
     if not training and running is None:
         raise ValueError("eval-mode BatchNorm needs the running statistics")
@@ -109,6 +113,8 @@ def resnet18_features(p, x, emulate_bf16=False, stats=None, taps=None, layers=LA
         w = p[name]
         if e:
             w = _RoundBF16.apply(w)
+        if acc64:
+            return _r(F.conv2d(t.double(), w.double(), None, stride, pad).float(), e)
         return _r(F.conv2d(t, w, None, stride, pad), e)
 
     def cbr(t, cname, bname, stride, pad, relu=True, residual=None):

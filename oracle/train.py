@@ -68,13 +68,15 @@ def train_gnn(p, cfg, train_records, val_records, *, lr, weight_decay, epochs, o
 
 
 def train_milnet(p, train_set, val_set, *, lr, weight_decay, epochs, per_step, seed, dropout=0.0, dropout_seed=0,
-                 layers=None, emulate_bf16=True, num_classes=7, aux_weight=1.0):
+                 layers=None, emulate_bf16=True, num_classes=7, aux_weight=1.0, acc64=False):
     """configs[1] loop on the CPU: the composed bag model (``oracle/model.py:milnet_forward``: ResNet-18 -> MIL teacher
     head -> radiomic fusion) trained with the loop shape of `01_train_mil_teacher.py:235-290` -- class-balanced sampler
     stream (`01:189-193`), ``per_step`` bags per AdamW step, evaluation of the validation bags after every epoch with the
     running BatchNorm statistics -- the like-for-like partner of ``isic_hip.train.train_milnet_fold`` (same sampler
     stream, same dropout words, same bf16 rounding points).  ``train_set`` / ``val_set`` = (images[n,K,3,S,S],
-    radiomics[n,R], labels[n]).  Returns (params, running buffers, history of {val_auc, val_bacc, val_loss, probs})."""
+    radiomics[n,R], labels[n]).  ``acc64``: the encoder's convolutions accumulate in float64 (oracle/resnet.py: the same
+    arithmetic in another summation order).  Returns (params, running buffers, history of {val_auc, val_bacc, val_loss,
+    probs, train_losses = the loss of every optimizer step of the epoch})."""
     import torch.nn.functional as F
     from . import model as omodel, resnet
     layers = layers or resnet.LAYERS
@@ -88,22 +90,27 @@ def train_milnet(p, train_set, val_set, *, lr, weight_decay, epochs, per_step, s
     step, hist = 0, []
     for _ in range(epochs):
         order = weighted_sample_indices(tlab, gen)
+        step_losses = []
         for s in range(0, len(order), per_step):
             idx = order[s:s + per_step]
             img = timg[idx].reshape(-1, *timg.shape[2:])
             offs = np.arange(len(idx) + 1) * K
             opt.zero_grad()
             out = omodel.milnet_forward(q, img, trad[idx], offs, emulate_bf16=emulate_bf16, layers=layers,
-                                        drop={"seed": dropout_seed, "step": step}, mil_dropout=dropout, running=running)
-            omodel.milnet_loss(out, torch.as_tensor(np.asarray(tlab)[idx]), aux_weight).backward()
+                                        drop={"seed": dropout_seed, "step": step}, mil_dropout=dropout, running=running,
+                                        acc64=acc64)
+            loss = omodel.milnet_loss(out, torch.as_tensor(np.asarray(tlab)[idx]), aux_weight)
+            loss.backward()
+            step_losses.append(float(loss.detach()))
             opt.step()
             step += 1
         with torch.no_grad():
             out = omodel.milnet_forward(q, vimg.reshape(-1, *vimg.shape[2:]), vrad, np.arange(len(vlab) + 1) * K,
-                                        emulate_bf16=emulate_bf16, layers=layers, running=running, training=False)
+                                        emulate_bf16=emulate_bf16, layers=layers, running=running, training=False, acc64=acc64)
             probs = torch.softmax(out["logits"], dim=1).numpy()
             vloss = float(F.cross_entropy(out["logits"], torch.as_tensor(np.asarray(vlab)).long()))
         y = np.asarray(vlab)
         hist.append({"val_auc": metrics.roc_auc_ovr_macro(y, probs, num_classes),
-                     "val_bacc": metrics.balanced_accuracy(y, probs.argmax(axis=1)), "val_loss": vloss, "probs": probs})
+                     "val_bacc": metrics.balanced_accuracy(y, probs.argmax(axis=1)), "val_loss": vloss, "probs": probs,
+                     "train_losses": step_losses})
     return {k: v.detach() for k, v in q.items()}, running, hist

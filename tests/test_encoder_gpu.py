@@ -271,6 +271,57 @@ def test_conv_pgemm_kernel(case):
         bf16_close(from_nhwc(got), F.conv2d(xr, wr, None, s, p), f"pgemm fwd {case}")
 
 
+PAIR_CASES = [  # N, H, W, C (block input channels), Co (planes): the three downsample blocks of ResNet-18 + odd sizes
+    (3, 12, 12, 64, 128),         # layer2.0: 64 outputs -> the one-tile-per-block kernel (conv_igemm<256, 64>)
+    (130, 28, 28, 64, 128),       # ... 1,6 k tiles per class: ragged last tiles
+    (5, 14, 14, 128, 256),        # layer3.0: the persistent short-K kernel (conv_pgemm), one 128-wide slice
+    (90, 14, 14, 256, 512),       # layer4.0: two slices, blocks shared out over the four classes
+    (2, 10, 14, 128, 128),        # H != W
+]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES)
+def test_downsample_block_data_gradients_in_one_launch(case):
+    """isic_conv2d_dgrad_pair_bf16: dgrad(3x3 / stride 2 / pad 1)(dy) + dgrad(1x1 / stride 2)(dy2) with the 1x1 term's
+    K-tiles appended to the even-pixel parity class of the 3x3 gradient -- against (a) the fp32 sum of torch's two
+    transposed convolutions on the same bf16 operands (one bf16 rounding), (b) the two-launch form it replaces
+    (isic_conv2d_igemm_bf16 twice, the 1x1 gradient as addend: that path rounds the 1x1 term to bf16 first, so the two
+    agree to one rounding of the larger term), and on the ODD pixels, which the 1x1 taps never reach, bit for bit."""
+    from torch.nn.grad import conv2d_input
+    from isic_hip.lib import call
+    N, H, W, C, Co = case
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    g = torch.Generator().manual_seed(21)
+    dy = torch.randn(N, Ho, Wo, Co, generator=g).to(DEV).to(BF)
+    dy2 = torch.randn(N, Ho, Wo, Co, generator=g).to(DEV).to(BF)
+    w3 = torch.randn(Co, C, 3, 3, generator=g) / np.sqrt(9 * C)
+    w1 = torch.randn(Co, C, 1, 1, generator=g) / np.sqrt(C)
+    wd3 = torch.empty(Co * C * 9, device=DEV, dtype=BF)
+    wd1 = torch.empty(Co * C, device=DEV, dtype=BF)
+    call("isic_conv_weight_prep_bf16", krsc(w3), None, wd3, Co, C, 3, 3)
+    call("isic_conv_weight_prep_bf16", krsc(w1), None, wd1, Co, C, 1, 1)
+    dx = torch.empty(N, H, W, C, device=DEV, dtype=BF)
+    call("isic_conv2d_dgrad_pair_bf16", dy, wd3, dy2, wd1, dx, N, Ho, Wo, Co, H, W, C)
+    # (b) the two launches
+    t1 = torch.empty(N, H, W, C, device=DEV, dtype=BF)
+    two = torch.empty(N, H, W, C, device=DEV, dtype=BF)
+    call("isic_conv2d_igemm_bf16", dy2, wd1, t1, N, Ho, Wo, Co, H, W, C, 1, 1, 1, 2, 0, None, None, None, 0)
+    call("isic_conv2d_igemm_bf16", dy, wd3, two, N, Ho, Wo, Co, H, W, C, 3, 3, 1, 2, 1, t1, None, None, 0)
+    torch.cuda.synchronize()
+    a, b = dx.float(), two.float()
+    odd = torch.ones(H, W, dtype=torch.bool, device=DEV)
+    odd[0::2, 0::2] = False
+    assert torch.equal(dx[:, odd], two[:, odd]), "pixels the 1x1 taps never reach must not change"
+    tol = (2.0 ** -7) * b.abs() + (2.0 ** -7) * t1.float().abs() + 1e-3 * float(b.abs().max())
+    assert not bool(((a - b).abs() > tol).any()), f"pair vs two launches {case}: max {float((a - b).abs().max()):.3e}"
+    assert float((dx != two).float().mean()) < 0.08          # a quarter of the pixels carry the extra rounding; most round alike
+    if N * H * W <= 4096:
+        dyr, dy2r = dy.float().cpu().permute(0, 3, 1, 2), dy2.float().cpu().permute(0, 3, 1, 2)
+        want = conv2d_input((N, C, H, W), w3.bfloat16().float(), dyr, stride=2, padding=1) + \
+            conv2d_input((N, C, H, W), w1.bfloat16().float(), dy2r, stride=2, padding=0)
+        bf16_close(from_nhwc(dx), want, f"pair data gradient {case}")
+
+
 @pytest.mark.parametrize("case", [(3, 10, 10, 128, 128), (70, 28, 28, 128, 128), (33, 14, 14, 256, 256), (65, 7, 7, 512, 512),
                                   (5, 9, 11, 128, 256)])
 @pytest.mark.parametrize("with_addend", [False, True])
