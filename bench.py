@@ -176,7 +176,7 @@ def kernel_source_hash(prefixes=None):
 
 # Which kernel files decide the HBM traffic of each roofline entry: a PMC profile stays valid while THESE are unchanged
 # (tests/test_host_cpu.py fails when a committed profile no longer matches, so a kernel commit cannot silently null it).
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
 TRAFFIC_SOURCES = {
     "mil": ("conv_igemm", "conv_halo", "conv_pgemm", "conv_c64"),      # kernels behind isic_conv2d_igemm_bf16
     "gnn": ("graph.",),                                                 # isic_spmm_csr_f32
@@ -186,7 +186,7 @@ TRAFFIC_SOURCES = {
 
 def pmc_traffic(section, **match):
     """HBM bytes per launch of a roofline entry from the rocprofv3 PMC passes of THIS command (counters need runs of
-    their own: tools/collect_traffic.sh writes profiles/r03_pmc_traffic.json).  Each section is stamped with the hash
+    their own: tools/collect_traffic.sh writes profiles/r04_pmc_traffic.json).  Each section is stamped with the hash
     of the kernel sources behind that entry and with the workload; anything that does not match the code being run is
     refused (-> None)."""
     try:
@@ -906,6 +906,98 @@ def run_knn(args, world, rank, dev):
     return line
 
 
+# ----------------------------------------------------------------------------------------------- configs[4]: the whole chain
+WORKLOAD_PIPELINE = ("Full pipeline (BASELINE.json configs[4]): 224x224 images -> frozen ViT-S/16 fp16 tokens [196 x 384] -> "
+                     "MIL teacher trained on the token bags (01) -> teacher outputs + dominant classes + all ten k-NN graphs on "
+                     "the device (02 / 03) -> edge heterophily (04) -> heterophily-aware GCNII trained on the knn8 graphs (05)")
+
+
+def run_pipeline(args, world, rank, dev):
+    """Per-stage wall time of the configs[4] chain on ``--pipeline-images`` synthetic images per GPU, everything resident in HBM
+    between the stages (pipeline.py).  Ranks are replicas of the chain (each on its own images); the value is images through
+    the WHOLE chain per second."""
+    import numpy as np
+    import measure_heterophily as mh
+    import pipeline
+    from gnn_models import GraphMIL
+    from isic_hip import train as T
+    from isic_hip.vit import ViTSmallEncoder
+    from utils_g_mil import AttentionMIL_teacher
+    n_img, C = args.pipeline_images, 7
+    n_val = max(C, n_img // 8)
+    torch.manual_seed(42)
+    enc = ViTSmallEncoder(img_size=224).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(77 + rank)
+    labels = (np.arange(n_img) + rank) % C
+    stages = {}
+
+    def timed(name, fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        stages[name] = time.perf_counter() - t0
+        return out
+
+    def encode():
+        toks = []
+        for lo in range(0, n_img, 512):                       # images are drawn on the device, 512 at a time (300 MB each)
+            n = min(512, n_img - lo)
+            x = torch.randn(n, 3, 224, 224, device=dev, generator=gen)
+            y = torch.as_tensor(labels[lo:lo + n], device=dev)
+            x += 0.6 * ((y.view(-1, 1, 1, 1) % 4).float() - 1.5)         # a class-dependent offset the teacher can learn
+            toks.append(enc.run_tokens(x))
+        return torch.cat(toks)                                 # [n_img, 196, 384] fp32, resident
+    enc.run_tokens(torch.randn(8, 3, 224, 224, device=dev, generator=gen))                        # warm-up (weight preparation)
+    tokens = timed("encode_vit_s16", encode)
+    tr_i, va_i = np.arange(n_val, n_img), np.arange(0, n_val)
+    teacher = AttentionMIL_teacher(384, 128, 64, dropout=0.5, num_classes=C).to(dev)
+    t_epochs = 2
+    timed("train_teacher", lambda: T.train_teacher_fold(teacher, [tokens[i] for i in tr_i], labels[tr_i], [tokens[i] for i in va_i],
+                                                        labels[va_i], lr=2.2e-4, epochs=t_epochs, patience=t_epochs,
+                                                        bags_per_step=256, device=dev, log=lambda *a, **k: None))
+    ids = [f"img_{i}" for i in range(n_img)]
+    outs = timed("teacher_outputs_and_all_k_knn", lambda: [
+        pipeline.collect_teacher_outputs_device(teacher, tokens[idx], labels[idx], [ids[i] for i in idx], dev) for idx in (tr_i, va_i)])
+    n_het = min(256, len(tr_i))
+
+    def heterophily():
+        ei = outs[0].knn_edge_index(8)[:n_het]
+        return mh.compute_edge_heterophily_batch(list(outs[0].x[:n_het].cpu().numpy()), list(outs[0].patch_probs[:n_het].cpu().numpy()),
+                                                 list(outs[0].dominant_class[:n_het].cpu().numpy()), list(ei.cpu().numpy()), device=str(dev))
+    timed("edge_heterophily", heterophily)
+    torch.manual_seed(1)
+    gnn = GraphMIL(384, "gcnii", 128, 3, 0.5, att_dim=128, att_heads=4, pool_dropout=0.2, classifier_dim=128, classifier_light=True,
+                   num_classes=C).to(dev)
+    g_epochs = 2
+    vm, _tm, _best = timed("train_gcnii_on_knn8", lambda: pipeline.train_gnn_from_teacher(
+        gnn, outs[0], outs[1], outs[1], "knn8", lr=1e-4, epochs=g_epochs, graphs_per_step=256, num_classes=C, device=dev,
+        rng=np.random.RandomState(2)))
+    total = sum(stages.values())
+    if world > 1:
+        t = torch.tensor([total], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        total = float(t.item())
+    if rank != 0:
+        return None
+    line = {"metric": "images/sec through the whole configs[4] chain (encode -> teacher -> graphs -> heterophily -> GNN)",
+            "value": world * n_img / total, "unit": "images/s", "n_gpus": world, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16 encoder, f32 heads", "data": "synthetic",
+            "config": {"workload": WORKLOAD_PIPELINE, "images_per_gpu": n_img, "validation_images": n_val, "teacher_epochs": t_epochs,
+                       "gnn_epochs": g_epochs, "heterophily_images": n_het, "parallelism": f"replicas{world}",
+                       "final_val_bacc_gnn": float(vm["bacc"])},
+            "seconds_per_stage": {k: round(v, 4) for k, v in stages.items()},
+            "per_stage_rate": {"encode_images_per_s": n_img / stages["encode_vit_s16"],
+                               "teacher_bags_per_s": t_epochs * len(tr_i) / stages["train_teacher"],
+                               "graph_build_images_per_s": n_img / stages["teacher_outputs_and_all_k_knn"],
+                               "heterophily_images_per_s": n_het / stages["edge_heterophily"],
+                               "gnn_graphs_per_s": g_epochs * len(tr_i) / stages["train_gcnii_on_knn8"]},
+            "note": "stage times include their evaluation passes, host-side epoch bookkeeping and (heterophily) the export of its "
+                    "inputs to numpy as 04's interface takes them; rooflines and CPU baselines of the kernels behind each stage "
+                    "are on the vit / teacher / knn / gnn sub-lines"}
+    return line
+
+
 def host_threads():
     """CPUs this process may actually keep busy: the affinity mask clipped by the cgroup CPU quota.  On the GPU box
     `os.cpu_count()` is 256 and torch defaults to 128 threads, but the container's quota is 16 CPUs: measured there, a
@@ -978,7 +1070,7 @@ def base_line(metric, unit, value, world, args, elapsed, dtype):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", choices=("mil", "gnn", "vit", "teacher", "knn"), default="mil")
+    ap.add_argument("--config", choices=("mil", "gnn", "vit", "teacher", "knn", "pipeline"), default="mil")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
@@ -992,6 +1084,7 @@ def main():
     ap.add_argument("--teacher-hidden", type=int, default=128)
     ap.add_argument("--teacher-att", type=int, default=64)
     ap.add_argument("--knn-graphs-per-step", type=int, default=2048, help="knn: images per adjacency-build step PER GPU")
+    ap.add_argument("--pipeline-images", type=int, default=2048, help="pipeline: images per GPU through the configs[4] chain")
     ap.add_argument("--nodes", type=int, default=196)
     ap.add_argument("--feat", type=int, default=768)
     ap.add_argument("--hidden", type=int, default=128)
@@ -1045,7 +1138,8 @@ def main():
         if r == 0:
             line["tuned"] = tuned
         return line
-    runners = {"mil": run_mil, "gnn": run_gnn, "vit": run_vit, "teacher": run_teacher_both, "knn": run_knn}
+    runners = {"mil": run_mil, "gnn": run_gnn, "vit": run_vit, "teacher": run_teacher_both, "knn": run_knn,
+               "pipeline": run_pipeline}
     line = runners[args.config](args, world, rank, dev)
     if args.config == "mil" and not args.no_sublines:
         # BASELINE.json configs[3] and configs[4] ride on the SAME line (the driver parses one line): short runs of the
@@ -1054,7 +1148,7 @@ def main():
         sub_args = argparse.Namespace(**vars(args))
         sub_args.steps, sub_args.warmup = args.sub_steps, 3
         sub_args.cpu_budget_s = min(args.cpu_budget_s, 10.0)
-        for name in ("gnn", "vit", "teacher", "knn"):
+        for name in ("gnn", "vit", "teacher", "knn", "pipeline"):
             release_device_memory()
             try:
                 sub = runners[name](sub_args, world, rank, dev)

@@ -368,7 +368,7 @@ int conv2d_wgrad_dispatch(const uint16_t* x, const uint16_t* dy, float* dw, int 
     const size_t need = isic_wgrad_c128b_workspace_bytes(N, Hin, Win, Cin, Cout);
     if (need != 0) {
       if (workspace_bytes < need) return ISIC_ERR_WORKSPACE;
-      const int rc = isic_wgrad_c128b_launch(x, dy, dw, N, Hin, Win, Cin, Cout, workspace, ((variant >> 1) & 7) | ((variant >> 5) & 3) << 4, as_stream(stream));
+      const int rc = isic_wgrad_c128b_launch(x, dy, dw, N, Hin, Win, Cin, Cout, workspace, (variant >> 1) & 7, as_stream(stream));
       return rc != ISIC_OK ? rc : isic_launch_status();
     }
   }

@@ -54,9 +54,7 @@ __device__ __forceinline__ void glds16b(const void* gsrc, unsigned lds_dst) {
 }
 
 // ABL (test entry only): bit 0 = no MFMAs, bit 1 = no fragment reads, bit 2 = no LDS-DMA -- where a tile's time goes
-// DPAT: when a tile's nine LDS-DMA groups (of the NEXT tile) go out: 0 = one per MFMA group (groups 0-8 of 12), 1 = two per
-// group (groups 0-4), 2 = all nine in front of the first group
-template <int ABL, int DPAT = 0>
+template <int ABL>
 __global__ __launch_bounds__(512) void wgrad_c128b_kernel(WC128BArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
@@ -196,14 +194,8 @@ __global__ __launch_bounds__(512) void wgrad_c128b_kernel(WC128BArgs a) {
       for (int kh = 0; kh < 3; ++kh) {
         // the tile's nine DMA groups of the NEXT tile go out between the MFMA groups: 12 slots per tile, 9 used
         const int slot = s * 3 + kh;
-        if (DPAT == 0) { if (slot < NDMA) dma_one(slot, ahead, nstage, more); }
-        else if (DPAT == 1) {
-          if (2 * slot < NDMA) dma_one(2 * slot, ahead, nstage, more);
-          if (2 * slot + 1 < NDMA) dma_one(2 * slot + 1, ahead, nstage, more);
-        } else if (slot == 0) {
-#pragma unroll
-          for (int j = 0; j < NDMA; ++j) dma_one(j, ahead, nstage, more);
-        }
+        // (two per group in groups 0-4, or all nine in front of the first group: 0 .. +3 % slower -- when they go out is not it)
+        if (slot < NDMA) dma_one(slot, ahead, nstage, more);
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
@@ -290,19 +282,18 @@ int isic_wgrad_c128b_launch(const uint16_t* x, const uint16_t* dy, float* dw, in
   a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x; a.total_tiles = p.total_tiles;
   a.tiles_per_block = p.tiles_per_block; a.blocks_per_pair = p.blocks_per_pair;
   a.Cx = Cin; a.Cy = Cout; a.co_slices = Cout / 64; a.pack = p.pack; a.slot_shift = p.slot_shift; a.Wv = p.Wv;
-  const void* fns[10] = {(const void*)wgrad_c128b_kernel<0>, (const void*)wgrad_c128b_kernel<1>, (const void*)wgrad_c128b_kernel<2>,
-                         (const void*)wgrad_c128b_kernel<3>, (const void*)wgrad_c128b_kernel<4>, (const void*)wgrad_c128b_kernel<5>,
-                         (const void*)wgrad_c128b_kernel<6>, (const void*)wgrad_c128b_kernel<7>,
-                         (const void*)wgrad_c128b_kernel<0, 1>, (const void*)wgrad_c128b_kernel<0, 2>};
+  const void* fns[8] = {(const void*)wgrad_c128b_kernel<0>, (const void*)wgrad_c128b_kernel<1>, (const void*)wgrad_c128b_kernel<2>,
+                        (const void*)wgrad_c128b_kernel<3>, (const void*)wgrad_c128b_kernel<4>, (const void*)wgrad_c128b_kernel<5>,
+                        (const void*)wgrad_c128b_kernel<6>, (const void*)wgrad_c128b_kernel<7>};
   static IsicPerDeviceOnce once;
   if (isic_once_per_device(once, [&] {
         hipError_t e = hipSuccess;
-        for (int i = 0; i < 10 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALL);
+        for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALL);
         return e;
       }) != hipSuccess)
     return ISIC_ERR_LAUNCH;
   void* kargs[] = {&a};
-  if (hipLaunchKernel(fns[ablation >= 16 ? 8 + ((ablation >> 4) - 1) % 2 : (ablation & 7)], dim3(p.pairs * p.blocks_per_pair), dim3(512), kargs, LDS_ALL, stream) != hipSuccess)
+  if (hipLaunchKernel(fns[ablation & 7], dim3(p.pairs * p.blocks_per_pair), dim3(512), kargs, LDS_ALL, stream) != hipSuccess)
     return ISIC_ERR_LAUNCH;
   hipLaunchKernelGGL(wgrad_c128b_reduce_kernel, dim3(p.pairs * (SLICE_ELEMS / 64)), dim3(256), 0, stream, a.partial, dw,
                      p.blocks_per_pair, a.co_slices, Cin);

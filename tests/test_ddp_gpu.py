@@ -148,7 +148,7 @@ def test_bare_multi_gpu_launch_starts_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1",
            "--bags-per-step", "2", "--patches", "4", "--image-size", "64", "--no-cpu-baseline", "--sub-steps", "2",
-           "--graphs-per-step", "8", "--images-per-step", "8", "--teacher-bags-per-step", "8", "--knn-graphs-per-step", "16"]
+           "--graphs-per-step", "8", "--images-per-step", "8", "--teacher-bags-per-step", "8", "--knn-graphs-per-step", "16", "--pipeline-images", "48"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
     line = json.loads(r.stdout.strip().splitlines()[-1])
@@ -158,6 +158,7 @@ def test_bare_multi_gpu_launch_starts_its_own_ranks():
     assert line["teacher"]["n_gpus"] == 2 and line["teacher"]["value"] > 0 and line["teacher"]["tuned"]["value"] > 0
     assert line["knn"]["n_gpus"] == 2 and line["knn"]["value"] > 0 and line["knn"]["roofline"]["bound"] == "mfma"
     assert "hipGraph" in line["gnn"]["config"]["step_launch"] and "hipGraph" in line["teacher"]["config"]["step_launch"]
+    assert line["pipeline"]["n_gpus"] == 2 and line["pipeline"]["value"] > 0 and len(line["pipeline"]["seconds_per_stage"]) == 5
 
 
 def test_captured_gnn_step_under_data_parallelism_equals_the_eager_step():

@@ -249,7 +249,7 @@ def test_vit_encoder_host_surface_and_oracle():
 
 
 def test_committed_pmc_traffic_profile_matches_the_kernels():
-    """`roofline.traffic` comes from profiles/r03_pmc_traffic.json (rocprofv3 PMC passes, tools/collect_traffic.sh).
+    """`roofline.traffic` comes from profiles/r04_pmc_traffic.json (rocprofv3 PMC passes, tools/collect_traffic.sh).
     bench.py refuses a section stamped with other kernel sources, which silently nulled the field in BENCH_r02 -- so a
     kernel commit that invalidates the profile must fail HERE until the profile is re-collected."""
     import json
@@ -262,7 +262,7 @@ def test_committed_pmc_traffic_profile_matches_the_kernels():
         assert section in prof, f"{section}: no PMC traffic section; run tools/collect_traffic.sh on the GPU box"
         assert prof[section]["kernel_source_hash"] == bench.kernel_source_hash(prefixes), (
             f"{section}: kernels {prefixes} changed since the PMC traffic profile was taken; re-run "
-            f"SECTIONS={section} tools/collect_traffic.sh on the GPU box and commit profiles/r03_pmc_traffic.json")
+            f"SECTIONS={section} tools/collect_traffic.sh on the GPU box and commit profiles/r04_pmc_traffic.json")
         assert prof[section]["hbm_bytes_per_launch"] > 0
     # and bench.py's reader accepts it for the default workloads
     assert bench.pmc_traffic("mil", bags_per_step=32, patches=64, image_size=224) > 0

@@ -5,7 +5,7 @@
 #   FETCH_SIZE and WRITE_SIZE need separate passes (TCC has 4 slots: 3 + 2).  Units are KiB; on gfx950
 #   FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads, so it is DOUBLED
 #   (/opt/skills/guides/MI355X_MICROARCH.md, HBM section).
-# Output: profiles/r03_pmc_traffic.json (tracked; copied back through gpurun_out/traffic/), one section per entry,
+# Output: profiles/r04_pmc_traffic.json (tracked; copied back through gpurun_out/traffic/), one section per entry,
 # each stamped with the hash of the kernel sources behind it (bench.TRAFFIC_SOURCES) and its workload: bench.py
 # refuses a section whose stamp differs from the code it runs, and tests/test_host_cpu.py fails on a stale one.
 #   SECTIONS="mil gnn vit" (default) selects what to re-collect; other sections of an existing file are kept.
@@ -40,7 +40,7 @@ except Exception:
     res = {}
 # (kernel-name substrings of the entry, C-ABI launches per step or None = one launch per dispatch, step-marker kernel)
 SPEC = {
-    "mil": (("conv_igemm", "conv3x3_c64", "conv_halo", "conv_pgemm"), 38, "adam_step_kernel",
+    "mil": (("conv_igemm", "conv3x3_c64", "conv_halo", "conv_pgemm"), 35, "adam_step_kernel",
             {"bags_per_step": $B, "patches": 64, "image_size": 224}),
     "gnn": (("spmm_",), None, "adam_step_kernel", {"graphs_per_step": 256, "nodes": 196, "hidden": 128, "knn_k": 8}),
     "vit": (("gemm_f16_kernel",), None, None, {"images_per_step": 2048, "image_size": 224}),
@@ -67,6 +67,6 @@ for s in "$SECTIONS".split():
               "note": "FETCH_SIZE doubled (gfx950 wide-read correction); separate --pmc passes per counter"}
 json.dump(res, open(path, "w"), indent=1, sort_keys=True)
 os.makedirs("$OUT", exist_ok=True)
-json.dump(res, open("$OUT/r03_pmc_traffic.json", "w"), indent=1, sort_keys=True)
+json.dump(res, open("$OUT/r04_pmc_traffic.json", "w"), indent=1, sort_keys=True)
 print(json.dumps(res)[:1500])
 PY
