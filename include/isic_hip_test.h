@@ -28,6 +28,12 @@ int isic_test_conv2d_igemm_variant_bf16(const uint16_t* in, const uint16_t* w, u
                                         const uint16_t* addend, double* stat_sum, double* stat_sumsq, int stat_slots,
                                         int variant, void* stream);
 
+/* isic_conv2d_dgrad_pair_bf16 (same arguments) with the kernel choice pinned by `variant` as above (thousands digit 2: the
+ * persistent short-K kernel also for 64-channel outputs). */
+int isic_test_conv2d_dgrad_pair_variant_bf16(const uint16_t* dy, const uint16_t* w, const uint16_t* dy2, const uint16_t* w2,
+                                             uint16_t* dx, int N, int Ho, int Wo, int Co, int H, int W, int C, int variant,
+                                             void* stream);
+
 /* isic_conv2d_wgrad_bf16 (same arguments) with `variant` bits: 0 = shipped; 16 = the 32-output-channel all-taps kernel
  * (conv_wgrad_c128.hip) where the 64-channel one (conv_wgrad_c128b.hip) ships; on that kernel: 1 = the block order it does
  * NOT ship with (XCD-grouped co-slice blocks vs pair-major), 2 / 4 / 8 = MFMAs / fragment reads / LDS-DMA compiled out

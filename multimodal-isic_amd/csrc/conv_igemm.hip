@@ -520,8 +520,11 @@ int conv2d_dispatch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N,
   // short-K layers (stride-2 3x3 and its data gradient, 1x1 downsample): persistent blocks, register epilogue
   // (64-wide slices exist in conv_pgemm.hip but are not chosen: the data gradient of the 64 -> 128 stride-2 layer has 2-8
   //  K-tiles per tile and ran 0.73 ms there against 0.63 ms in the one-tile-per-block kernel, whose blocks overlap)
+  //  Round 4: the PAIR gradient of that layer (a second source: 2-8 -> 4-8 K-tiles per tile, no addend to read) does run
+  //  faster there: 0.66 against 0.82 ms at 2048 images (tools/halo_ab.py --pair), bit-equal.
   if (Cout % 64 == 0 && !(stat_sum && addend) && cv.pgemm != 1 &&
-      (cv.pgemm == 2 || (Cout % 128 == 0 && (up != 1 || (down != 1 && Kh * Kw > 1) || (Kh == 1 && Kw == 1 && down == 1))))) {
+      (cv.pgemm == 2 || in2 != nullptr ||
+       (Cout % 128 == 0 && (up != 1 || (down != 1 && Kh * Kw > 1) || (Kh == 1 && Kw == 1 && down == 1))))) {
     const int rc = isic_conv_pgemm_launch(all, s);
     return rc != ISIC_OK ? rc : isic_launch_status();
   }
@@ -561,6 +564,14 @@ int isic_conv2d_dgrad_pair_bf16(const uint16_t* dy, const uint16_t* w, const uin
   ISIC_CHECK_ARG(dy && w && dy2 && w2 && dx);
   return conv2d_dispatch(dy, w, dx, N, Ho, Wo, Co, H, W, C, 3, 3, 1, 2, 1, nullptr, nullptr, nullptr, 0, 0, stream, nullptr,
                          dy2, w2);
+}
+
+int isic_test_conv2d_dgrad_pair_variant_bf16(const uint16_t* dy, const uint16_t* w, const uint16_t* dy2, const uint16_t* w2,
+                                             uint16_t* dx, int N, int Ho, int Wo, int Co, int H, int W, int C, int variant,
+                                             void* stream) {
+  ISIC_CHECK_ARG(dy && w && dy2 && w2 && dx);
+  return conv2d_dispatch(dy, w, dx, N, Ho, Wo, Co, H, W, C, 3, 3, 1, 2, 1, nullptr, nullptr, nullptr, 0, variant, stream,
+                         nullptr, dy2, w2);
 }
 
 size_t isic_conv2d_maskadd_supported(int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int Kh, int Kw, int up,

@@ -142,7 +142,10 @@ def colsum(x, out=None, beta=0.0):
     if out is None:
         out = torch.empty((x.shape[1],), device=x.device, dtype=torch.float32)
     ws = _workspace(call("isic_colsum_f32_workspace_bytes", x.shape[0], x.shape[1]), x.device)
-    call("isic_colsum_f32_ws", x, x.shape[0], x.shape[1], x.stride(0), out, float(beta), ws,
+    if x.dim() != 2 or (x.shape[1] > 1 and x.stride(1) != 1) or not x.is_cuda or x.dtype != torch.float32:
+        raise IsicHipError("colsum takes a 2-D fp32 device tensor with unit inner stride (a column slice of a matrix is fine)")
+    xp = x if x.is_contiguous() else x.data_ptr()        # a column slice: the kernel walks rows by x.stride(0)
+    call("isic_colsum_f32_ws", xp, x.shape[0], x.shape[1], x.stride(0), out, float(beta), ws,
          ws.numel() if ws is not None else 0)
     return out
 
@@ -397,6 +400,7 @@ class AttnPoolFn(torch.autograd.Function):
              BL, BP)
         ctx.dims = (B, H, A, heads, C, int(max_bag))
         ctx.teacher = teacher
+        ctx.params = (W2, b2, w3, b3, W4, b4)          # the callers' tensors: Parameters take their gradients in place
         ctx.save_for_backward(h, t, att, P, _f32c(W2), w3c, W4c, offsets)
         if teacher:
             ctx.mark_non_differentiable(att, P, PP, BP)
@@ -417,6 +421,13 @@ class AttnPoolFn(torch.autograd.Function):
         d_u = torch.empty((T, heads * A), device=dev, dtype=torch.float32)
         d_s = torch.empty((T, heads), device=dev, dtype=torch.float32)
         d_P = torch.empty((T, C), device=dev, dtype=torch.float32) if ctx.teacher else None
+        # Parameters whose .grad lives in the flat gradient buffer (optim.FlatParams) are accumulated INTO by the reduction
+        # kernels themselves (GEMM beta = 1, column sums with beta = 1): no gradient tensor, no AccumulateGrad add launch
+        # (six of them per teacher step: 11 % of a 0.63 ms step at 256 bags)
+        pW2, pb2, pw3, pb3, pW4, pb4 = ctx.params
+        tW2, tb2, tw3, tb3 = _acc_target(pW2), _acc_target(pb2), _acc_target(pw3), _acc_target(pb3)
+        small_fused = tb2 is not None and tw3 is not None and tb3 is not None
+        db2 = dw3 = db3 = None
         if H <= 128 and A <= 128:
             # db2 = sum_n d_u, dw3[k, j] = sum_n d_s[n,k] t[n, kA+j], db3 = sum_n d_s: per-bag sums out of the pool kernel
             # (d_u and t are in its registers), then ONE column sum over the bags
@@ -424,26 +435,48 @@ class AttnPoolFn(torch.autograd.Function):
             psum = torch.empty((B, 2 * nA + heads), device=dev, dtype=torch.float32)
             call("isic_attn_pool_bwd_sums", h, t, att, P, w3c, W4c, offsets, B, H, A, heads, C, max_bag, dBL, dz, d_h, 0,
                  d_u, d_s, d_P, psum)
-            sums = colsum(psum)
-            db2, dw3, db3 = sums[:nA], sums[nA:2 * nA].view(heads, A), sums[2 * nA:]
+            if small_fused:
+                colsum(psum[:, :nA], out=tb2.view(-1), beta=1.0)
+                colsum(psum[:, nA:2 * nA], out=tw3.view(-1), beta=1.0)
+                colsum(psum[:, 2 * nA:], out=tb3.view(-1), beta=1.0)
+            else:
+                sums = colsum(psum)
+                db2, dw3, db3 = sums[:nA], sums[nA:2 * nA].view(heads, A), sums[2 * nA:]
         else:
             call("isic_attn_pool_bwd", h, t, att, P, w3c, W4c, offsets, B, H, A, heads, C, max_bag, dBL, dz, d_h, 0, d_u,
                  d_s, d_P)
-            db2 = colsum(d_u)
             # dw3[k, j] = sum_n d_s[n,k] * t[n, k*A + j]
-            if heads == 1:
-                dw3 = gemm(d_s, t, trans_a=True)                 # [1, A]
+            if small_fused and heads == 1:
+                colsum(d_u, out=tb2.view(-1), beta=1.0)
+                gemm(d_s, t, trans_a=True, out=tw3.view(1, A), beta=1.0)
+                colsum(d_s, out=tb3.view(-1), beta=1.0)
             else:
-                full = gemm(d_s, t, trans_a=True)                # [heads, heads*A]
-                dw3 = torch.stack([full[k, k * A:(k + 1) * A] for k in range(heads)])
-            db3 = colsum(d_s)
+                small_fused = False
+                db2 = colsum(d_u)
+                if heads == 1:
+                    dw3 = gemm(d_s, t, trans_a=True)                 # [1, A]
+                else:
+                    full = gemm(d_s, t, trans_a=True)                # [heads, heads*A]
+                    dw3 = torch.stack([full[k, k * A:(k + 1) * A] for k in range(heads)])
+                db3 = colsum(d_s)
         # weight gradient of the first Linear: a GEMM over the T instances
-        dW2 = gemm(d_u, h, trans_a=True)                     # [heads*A, H]
+        if tW2 is not None:
+            gemm(d_u, h, trans_a=True, out=tW2, beta=1.0)
+            dW2 = None
+        else:
+            dW2 = gemm(d_u, h, trans_a=True)                 # [heads*A, H]
         gemm(d_u, W2, out=d_h, beta=1.0)                     # d_h += d_u W2
         dW4 = db4 = None
         if ctx.teacher:
-            dW4 = gemm(d_P, h, trans_a=True)
-            db4 = colsum(d_P)
+            tW4, tb4 = _acc_target(pW4), _acc_target(pb4)
+            if tW4 is not None:
+                gemm(d_P, h, trans_a=True, out=tW4, beta=1.0)
+            else:
+                dW4 = gemm(d_P, h, trans_a=True)
+            if tb4 is not None:
+                colsum(d_P, out=tb4, beta=1.0)
+            else:
+                db4 = colsum(d_P)
         return d_h, dW2, db2, dw3, db3, dW4, db4, None, None, None
 
 

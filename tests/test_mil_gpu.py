@@ -117,6 +117,40 @@ def test_adamw_three_steps_golden():
             assert_close(v, g[f"step{s}.{k}"], rtol=2e-5, atol=2e-7, what=f"step{s}.{k}")
 
 
+@pytest.mark.parametrize("dims", [(196, 96, 128, 64, 7), (50, 64, 136, 144, 5)])      # pool-kernel sums (H, A <= 128) / the wide path
+def test_teacher_gradients_accumulated_in_place_equal_autograd_accumulation(dims):
+    """`ops.fused_grad_accumulation`: the attention pool's backward adds dW2 / db2 / dw3 / db3 / dW4 / db4 straight into the
+    flat gradient buffer (GEMM beta = 1, column sums with beta = 1 on column slices of the per-bag sums) instead of
+    returning six tensors for six AccumulateGrad launches -- same gradients (1e-6 of their scale), also on top of a
+    gradient that is already there."""
+    import utils_g_mil
+    from isic_hip import ops, optim
+    from isic_hip.bags import BagOffsets
+    K, D, H, A, C = dims
+    torch.manual_seed(3)
+    m = utils_g_mil.AttentionMIL_teacher(D, H, A, 0.3, C).to(DEV)
+    m.train()
+    opt = optim.AdamW(m.parameters(), lr=1e-3)
+    gen = torch.Generator().manual_seed(4)
+    B = 9
+    x = torch.randn(B * K, D, generator=gen).to(DEV)
+    y = (torch.arange(B) % C).to(DEV)
+    offs = BagOffsets.uniform(B, K, torch.device(DEV))
+
+    def grads(fused, times):
+        opt.zero_grad()
+        for _ in range(times):
+            m.set_dropout_state(seed=8, step=0)
+            with ops.fused_grad_accumulation(fused):
+                ops.cross_entropy(m(x, offs)["bag_logits"], y).backward()
+        torch.cuda.synchronize()
+        return opt.flat.grad.clone()
+    for times in (1, 2):
+        a, b = grads(False, times), grads(True, times)
+        assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()) + 1e-9, (dims, times)
+        assert float(a.abs().max()) > 0
+
+
 def test_cpu_tensor_is_rejected():
     import utils_g_mil
     from isic_hip.lib import IsicHipError

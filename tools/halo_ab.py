@@ -39,6 +39,31 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
+def pair_ab(a):
+    N = a.n
+    for name, C, Co, H in (("l2.0", 64, 128, 56), ("l3.0", 128, 256, 28), ("l4.0", 256, 512, 14)):
+        Ho = H // 2
+        dy = torch.randn(N, Ho, Ho, Co, device=DEV).to(BF)
+        dy2 = torch.randn(N, Ho, Ho, Co, device=DEV).to(BF)
+        w3 = (torch.randn(Co, C, 3, 3, device=DEV) / (C * 9) ** 0.5).contiguous(memory_format=torch.channels_last)
+        w1 = (torch.randn(Co, C, 1, 1, device=DEV) / C ** 0.5).contiguous(memory_format=torch.channels_last)
+        wd3, wd1 = torch.empty(Co * C * 9, device=DEV, dtype=BF), torch.empty(Co * C, device=DEV, dtype=BF)
+        call("isic_conv_weight_prep_bf16", w3, None, wd3, Co, C, 3, 3)
+        call("isic_conv_weight_prep_bf16", w1, None, wd1, Co, C, 1, 1)
+        gf = 2.0 * N * Ho * Ho * Co * C * 10 / 1e9
+        variants = [0, 2000]
+        outs = [torch.zeros(N, H, H, C, device=DEV, dtype=BF) for _ in variants]
+        fns = [(lambda v=v, o=o: call("isic_test_conv2d_dgrad_pair_variant_bf16", dy, wd3, dy2, wd1, o, N, Ho, Ho, Co, H, H, C, v))
+               for v, o in zip(variants, outs)]
+        for f in fns:
+            f()
+        torch.cuda.synchronize()
+        ts = interleaved(fns, a.iters)
+        for v, o, t in zip(variants, outs, ts):
+            same = "bit-equal" if torch.equal(o, outs[0]) else f"differs max {float((o.float() - outs[0].float()).abs().max()):.3e}"
+            print(f"{name} pair dgrad variant {v:4d}: {t:7.4f} ms  {gf / t:7.0f} TF/s alg  {same}", flush=True)
+
+
 def wgrad_ab(a):
     N = a.n
     variants = [int(v) for v in a.exps.split(",")]
@@ -67,10 +92,13 @@ def main():
     ap.add_argument("--exps", default="0,1", help="conv: 0 = shipped kernel, 1 = the round-3 K loop; --wgrad: variant bits")
     ap.add_argument("--layers", default="l2,l3,l4")
     ap.add_argument("--addend", action="store_true", help="also the data gradient with a residual-gradient addend")
+    ap.add_argument("--pair", action="store_true", help="A/B of the downsample-block pair data gradient: variants 0 and 2000")
     ap.add_argument("--wgrad", action="store_true", help="A/B of the weight-gradient block orders instead (isic_test_conv2d_wgrad_variant_bf16)")
     a = ap.parse_args()
     if a.wgrad:
         return wgrad_ab(a)
+    if a.pair:
+        return pair_ab(a)
     N = a.n
     exps = [int(v) for v in a.exps.split(",")]
     for name in a.layers.split(","):
