@@ -295,7 +295,8 @@ __device__ __forceinline__ void store16_v(void* ptr, u32x4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
 }
 
-template <bool STATS, bool ADDEND>
+// ABL (test entry only; results are garbage): bit 0 = no MFMAs, bit 1 = no fragment reads, bit 2 = no LDS-DMA, bit 3 = no stores
+template <bool STATS, bool ADDEND, int ABL = 0>
 __global__ __launch_bounds__(512) void conv3x3_c64p_kernel(C64PArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef __attribute__((address_space(3))) float lds_float;
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64p_kernel(C64PArgs a) {
     const bool real = live && ddst[j] != 0xFFFFFFFFu;
     const bool ok = real && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
     const unsigned char* src = (ok ? origin + doff[j] : g_c64_zeros) + lane_src;
-    glds16(src, real ? lds0 + (unsigned)buf * P_BUF + ddst[j] : lds0 + P_SCRATCH);
+    if (!(ABL & 4)) glds16(src, real ? lds0 + (unsigned)buf * P_BUF + ddst[j] : lds0 + P_SCRATCH);
   };
   auto issue_patch = [&](const Tile& tl, int buf, bool live) {
 #pragma unroll
@@ -453,7 +454,8 @@ __global__ __launch_bounds__(512) void conv3x3_c64p_kernel(C64PArgs a) {
         }
       }
       // exactly one store per M-tile is ISSUED whatever the validity (see CNT_TOP)
-      if (seg == 0) store16_s(a.out + off, lane_out, v);
+      if (ABL & 8) { asm volatile("" :: "v"(v)); }
+      else if (seg == 0) store16_s(a.out + off, lane_out, v);
       else if (seg == 1) store16_s(g_c64_sink, (unsigned)lane * 16, v);
       else store16_v(valid ? (void*)(reinterpret_cast<unsigned char*>(a.out + off) + lane_out) : (void*)(g_c64_sink + lane * 16), v);
     }
@@ -463,9 +465,10 @@ __global__ __launch_bounds__(512) void conv3x3_c64p_kernel(C64PArgs a) {
   // when iteration kk starts.  The waves of channel half 0 run  [DMA kk+2 + MFMAs kk, addend loads kk, stores kk]  per
   // iteration, those of half 1 DEFER the epilogue behind the next barrier --  [addend loads kk-1, stores kk-1,
   // DMA kk+2 + MFMAs kk]  -- so that on every SIMD one wave's epilogue runs under the other wave's MFMAs.
-  constexpr int NEPI = 4 + (ADDEND ? 8 : 0);            // memory operations of one epilogue (stores; addend + its mask byte)
-  constexpr int CNT_TOP0 = NEPI + P_DMA + NEPI;         // epilogue(kk-2), DMA(kk+1), epilogue(kk-1)
-  constexpr int CNT_TOP1 = NEPI + P_DMA;                // epilogue(kk-2), DMA(kk+1)
+  constexpr int NEPI = ((ABL & 8) ? 0 : 4) + (ADDEND ? 8 : 0);   // memory operations of one epilogue (stores; addend + its mask byte)
+  constexpr int NDMA_T = (ABL & 4) ? 0 : P_DMA;
+  constexpr int CNT_TOP0 = NEPI + NDMA_T + NEPI;        // epilogue(kk-2), DMA(kk+1), epilogue(kk-1)
+  constexpr int CNT_TOP1 = NEPI + NDMA_T;               // epilogue(kk-2), DMA(kk+1)
   if (STATS) lds_barrier();                             // statistics slots zeroed
 
   Tile prev = cur;
@@ -488,7 +491,10 @@ __global__ __launch_bounds__(512) void conv3x3_c64p_kernel(C64PArgs a) {
       const int tap = s >> 1, ks = s & 1, kh = tap / 3, kw = tap % 3;
       const unsigned char* q = patch + (abase[kw] ^ (ks << 6));
 #pragma unroll
-      for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const bf16x8*>(q + (((i >> 1) + kh) * PP + (i & 1) * 16) * 128);
+      for (int i = 0; i < 4; ++i) {
+        if (ABL & 2) { const unsigned u = abase[kw] + i + s; f[i] = __builtin_bit_cast(bf16x8, (u32x4){u, u, u, u}); asm volatile("" : "+v"(f[i])); }
+        else f[i] = *reinterpret_cast<const bf16x8*>(q + (((i >> 1) + kh) * PP + (i & 1) * 16) * 128);
+      }
     };
     read_step(0, af[0]);
 #pragma unroll
@@ -498,9 +504,11 @@ __global__ __launch_bounds__(512) void conv3x3_c64p_kernel(C64PArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[s >> 1][s & 1][j], af[s & 1][i],
-                                                              s == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+          if (ABL & 1) { if (j == 0) asm volatile("" :: "v"(af[s & 1][i])); if (s == 0) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[s >> 1][s & 1][j], af[s & 1][i],
+                                                                   s == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[i][j], 0, 0, 0);
+        }
       __builtin_amdgcn_sched_barrier(0);       // keep the fragment reads of later steps from piling up in registers
     }
     C64P_STAMP(kk, 2);
@@ -535,15 +543,15 @@ __global__ __launch_bounds__(512) void conv3x3_c64p_kernel(C64PArgs a) {
   }
 }
 
-template <bool STATS, bool ADDEND>
+template <bool STATS, bool ADDEND, int ABL = 0>
 int launch_c64p(const C64PArgs& a, int grid, hipStream_t stream) {
   static IsicPerDeviceOnce once;              // hipFuncSetAttribute is per device (one flag set per template instance)
   if (isic_once_per_device(once, [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64p_kernel<STATS, ADDEND>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64p_kernel<STATS, ADDEND, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   P_LDS);
       }) != hipSuccess)
     return ISIC_ERR_LAUNCH;
-  hipLaunchKernelGGL((conv3x3_c64p_kernel<STATS, ADDEND>), dim3(grid), dim3(512), P_LDS, stream, a);
+  hipLaunchKernelGGL((conv3x3_c64p_kernel<STATS, ADDEND, ABL>), dim3(grid), dim3(512), P_LDS, stream, a);
   return ISIC_OK;
 }
 
@@ -553,7 +561,7 @@ int launch_c64p(const C64PArgs& a, int grid, hipStream_t stream) {
 // variant 2 = persistent blocks with register-resident weights
 int isic_conv3x3_c64_launch(int variant, const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int H, int W,
                             const uint16_t* addend, const uint8_t* addend_mask, double* stat_sum, double* stat_sumsq,
-                            int stat_slots, hipStream_t stream) {
+                            int stat_slots, int experiment, hipStream_t stream) {
   const int tiles_y = ceil_div(H, TH), tiles_x = ceil_div(W, TW);
   const int64_t blocks = (int64_t)N * tiles_y * tiles_x;
   if (blocks > 0x7FFFFFFFLL) return ISIC_ERR_UNSUPPORTED;
@@ -566,6 +574,18 @@ int isic_conv3x3_c64_launch(int variant, const uint16_t* in, const uint16_t* w, 
     a.total_tiles = (int)blocks;
     a.tiles_per_block = ceil_div(a.total_tiles, cus);
     const int grid = ceil_div(a.total_tiles, a.tiles_per_block);       // every block owns at least one tile
+    if (experiment >= 2) {                                 // timing ablations: experiment digit e -> where the time goes
+      if (stat_sum || addend) return ISIC_ERR_UNSUPPORTED;
+      switch (experiment) {
+        case 2: return launch_c64p<false, false, 1>(a, grid, stream);     // no MFMAs
+        case 3: return launch_c64p<false, false, 8>(a, grid, stream);     // no stores
+        case 4: return launch_c64p<false, false, 4>(a, grid, stream);     // no DMA
+        case 5: return launch_c64p<false, false, 12>(a, grid, stream);    // no DMA, no stores: MFMA + fragment reads
+        case 6: return launch_c64p<false, false, 11>(a, grid, stream);    // DMA only
+        case 7: return launch_c64p<false, false, 7>(a, grid, stream);     // stores only
+        default: return ISIC_ERR_UNSUPPORTED;
+      }
+    }
     if (stat_sum) return launch_c64p<true, false>(a, grid, stream);
     if (addend) return launch_c64p<false, true>(a, grid, stream);
     return launch_c64p<false, false>(a, grid, stream);

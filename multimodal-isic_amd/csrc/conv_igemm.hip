@@ -407,7 +407,7 @@ constexpr int kDefaultConvC64 = 2;    // 64 -> 64 3x3 layers: persistent halo ke
 
 int isic_conv3x3_c64_launch(int variant, const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int H, int W,
                             const uint16_t* addend, const uint8_t* addend_mask, double* stat_sum, double* stat_sumsq,
-                            int stat_slots, hipStream_t stream);
+                            int stat_slots, int experiment, hipStream_t stream);
 bool isic_conv_halo_supported(int N, int H, int W, int Cin, int Cout);
 int isic_conv_halo_launch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int H, int W, int Cin, int Cout,
                           const uint16_t* addend, const uint8_t* addend_mask, double* stat_sum, double* stat_sumsq,
@@ -469,7 +469,7 @@ int conv2d_dispatch(const uint16_t* in, const uint16_t* w, uint16_t* out, int N,
   const bool same3x3 = Kh == 3 && Kw == 3 && up == 1 && down == 1 && pad == 1 && Hin == Hout && Win == Wout;
   if (Cin == 64 && Cout == 64 && same3x3 && cv.c64 != 0) {
     const int rc = isic_conv3x3_c64_launch(cv.c64, in, w, out, N, Hin, Win, addend, addend_mask, stat_sum, stat_sumsq,
-                                           stat_slots, as_stream(stream));
+                                           stat_slots, cv.exp, as_stream(stream));
     return rc != ISIC_OK ? rc : isic_launch_status();
   }
   // >= 128-channel 3x3 layers: every input pixel staged once for all nine taps (conv_halo.hip)
