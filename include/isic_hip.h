@@ -518,6 +518,13 @@ int isic_maxpool3x3s2_bwd_bf16(const uint8_t* argmax, const uint16_t* dy, uint16
  * instead of the full output tensor -- same results as the y-based forms below, ~2 B/element less traffic per pass. */
 int isic_bn_apply_mask_bf16(const uint16_t* x, const float* scale, const float* shift, const uint16_t* residual,
                             uint16_t* y, uint8_t* relu_mask, int64_t rows, int C, void* stream);
+/* ... with a residual that is itself a RAW convolution output under a BatchNorm without ReLU (the 1x1 shortcut of a
+ * downsample block, torchvision BasicBlock.downsample): y = relu(x * scale + shift + bf16(residual_raw * res_scale + res_shift)).
+ * The shortcut's normalised tensor is never written; the inner rounding keeps the result bit-identical to
+ * isic_bn_apply_bf16(residual_raw -> idn) + isic_bn_apply_mask_bf16(residual = idn). */
+int isic_bn_apply_mask_res_affine_bf16(const uint16_t* x, const float* scale, const float* shift, const uint16_t* residual_raw,
+                                       const float* res_scale, const float* res_shift, uint16_t* y, uint8_t* relu_mask,
+                                       int64_t rows, int C, void* stream);
 int isic_bn_bwd_reduce_mask_bf16(const uint16_t* dy, const uint16_t* x, const uint8_t* relu_mask, const float* mean,
                                  const float* rstd, int64_t rows, int C, double* dgamma, double* dbeta, void* stream);
 int isic_bn_bwd_apply_mask_bf16(const uint16_t* dy, const uint16_t* x, const uint8_t* relu_mask, const float* mean,

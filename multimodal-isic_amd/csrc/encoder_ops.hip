@@ -120,17 +120,23 @@ __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const flo
   shift[c] = beta[c] - rm[c] * sc;
 }
 
+template <bool RES_AFFINE>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __restrict__ x,
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ shift,
                                                         const unsigned short* __restrict__ residual,
                                                         unsigned short* __restrict__ y,
-                                                        unsigned char* __restrict__ relu_mask, int64_t nvec, int C, int relu) {
+                                                        unsigned char* __restrict__ relu_mask, int64_t nvec, int C, int relu,
+                                                        const float* __restrict__ res_scale,
+                                                        const float* __restrict__ res_shift) {
   // a block starts at a multiple of 256 vectors and 256 % (C/8) == 0, so a thread always sees the same 8 channels
   const int cg = threadIdx.x % (C >> 3);
-  float sc[8], sh[8];
+  float sc[8], sh[8], rsc[8], rsh[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { sc[j] = scale[cg * 8 + j]; sh[j] = shift[cg * 8 + j]; }
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = scale[cg * 8 + j]; sh[j] = shift[cg * 8 + j];
+    rsc[j] = RES_AFFINE ? res_scale[cg * 8 + j] : 1.f; rsh[j] = RES_AFFINE ? res_shift[cg * 8 + j] : 0.f;
+  }
   // FLAT_APPLY consecutive 256-vector rows per block, one vector of each per thread, no loop over the tensor
   // (tests/probes/probe_stream.hip: 6.1-6.4 TB/s; a grid of 8192 blocks striding the tensor: 5.2)
   const int64_t base = (int64_t)blockIdx.x * (256 * FLAT_APPLY) + threadIdx.x;
@@ -144,7 +150,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = f[j] * sc[j] + sh[j];
-      if (residual) v += rsd[j];
+      // res_scale / res_shift: the residual is a RAW convolution output (a downsample block's 1x1 shortcut) normalised here,
+      // rounded to bf16 exactly as the pass that used to materialise it did -- bit-identical, one write + one read less
+      if (residual) v += RES_AFFINE ? bf16_bits_to_f32(f32_to_bf16_bits(rsd[j] * rsc[j] + rsh[j])) : rsd[j];
       if (relu) v = fmaxf(v, 0.f);
       f[j] = v;
     }
@@ -663,8 +671,8 @@ int isic_bn_apply_bf16(const uint16_t* x, const float* scale, const float* shift
   ISIC_CHECK_ARG(x && scale && shift && y && rows > 0 && C > 0 && C % 8 == 0);
   if (!bn_c_ok(C)) return ISIC_ERR_UNSUPPORTED;   // per-thread channel constants: C/8 must divide the 256-thread block
   const int64_t nvec = rows * (C / 8);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(nvec, 256 * FLAT_APPLY, STREAM_CAP)), dim3(256), 0, as_stream(stream), x, scale, shift,
-                     residual, y, nullptr, nvec, C, relu);
+  hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(grid_for(nvec, 256 * FLAT_APPLY, STREAM_CAP)), dim3(256), 0, as_stream(stream), x, scale, shift,
+                     residual, y, nullptr, nvec, C, relu, nullptr, nullptr);
   return isic_launch_status();
 }
 
@@ -673,8 +681,19 @@ int isic_bn_apply_mask_bf16(const uint16_t* x, const float* scale, const float* 
   ISIC_CHECK_ARG(x && scale && shift && y && relu_mask && rows > 0 && C > 0 && C % 8 == 0);
   if (!bn_c_ok(C)) return ISIC_ERR_UNSUPPORTED;   // per-thread channel constants: C/8 must divide the 256-thread block
   const int64_t nvec = rows * (C / 8);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(nvec, 256 * FLAT_APPLY, STREAM_CAP)), dim3(256), 0, as_stream(stream), x, scale, shift,
-                     residual, y, relu_mask, nvec, C, 1);
+  hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(grid_for(nvec, 256 * FLAT_APPLY, STREAM_CAP)), dim3(256), 0, as_stream(stream), x, scale, shift,
+                     residual, y, relu_mask, nvec, C, 1, nullptr, nullptr);
+  return isic_launch_status();
+}
+
+int isic_bn_apply_mask_res_affine_bf16(const uint16_t* x, const float* scale, const float* shift, const uint16_t* residual_raw,
+                                       const float* res_scale, const float* res_shift, uint16_t* y, uint8_t* relu_mask,
+                                       int64_t rows, int C, void* stream) {
+  ISIC_CHECK_ARG(x && scale && shift && residual_raw && res_scale && res_shift && y && relu_mask && rows > 0 && C > 0 && C % 8 == 0);
+  if (!bn_c_ok(C)) return ISIC_ERR_UNSUPPORTED;
+  const int64_t nvec = rows * (C / 8);
+  hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(grid_for(nvec, 256 * FLAT_APPLY, STREAM_CAP)), dim3(256), 0, as_stream(stream), x, scale, shift,
+                     residual_raw, y, relu_mask, nvec, C, 1, res_scale, res_shift);
   return isic_launch_status();
 }
 

@@ -99,6 +99,7 @@ class ResNet18Encoder(nn.Module):
         self.mask_identity_gradient = True
         # downsample blocks: both stride-2 data gradients in one launch (A/B attribute; one bf16 rounding less than two launches)
         self.pair_downsample_gradient = True
+        self.fold_shortcut_norm = True      # downsample blocks: the shortcut's BatchNorm output is not materialised (training)
         self._tape_fused = False      # fusion mode of the tape being replayed (recorded at forward time)
         self.grad_ready_hook = None   # callable(list_of_param_names) fired as gradients complete (DDP overlap)
 
@@ -326,11 +327,18 @@ class ResNet18Encoder(nn.Module):
         ws = self._workspace(call("isic_conv2d_wgrad_workspace_bytes", N, C, Ho, Wo, Co, sp.k, sp.k), x.device)
         call("isic_conv2d_wgrad_bf16", x, dy, g, N, H, W, C, Ho, Wo, Co, sp.k, sp.k, sp.stride, sp.pad, ws, ws.numel())
 
-    def _bn_fwd(self, c, name, relu, residual=None, acc=None):
-        """Returns (y, (mean, rstd, scale, shift)).  ``acc`` = fused statistics from the producing conv."""
+    def _bn_fwd(self, c, name, relu, residual=None, acc=None, residual_affine=None):
+        """Returns (y, (mean, rstd, scale, shift)).  ``acc`` = fused statistics from the producing conv.
+        ``residual_affine`` = (scale, shift): ``residual`` is a RAW convolution output normalised on the fly (a downsample
+        block's shortcut: its BatchNorm's output is never written)."""
         st = self._bn_affine(c, name, acc)
         N, H, W, C = c.shape
         y = _empty(c.shape, c)
+        if residual_affine is not None:
+            mask = torch.empty((N * H * W * C) // 8, device=c.device, dtype=torch.uint8)
+            call("isic_bn_apply_mask_res_affine_bf16", c, st[2], st[3], residual, residual_affine[0], residual_affine[1], y, mask,
+                 N * H * W, C)
+            return y, st + (mask,)
         if relu and self.training and (residual is not None or self.fuse_bn_backward):
             # the backward passes need the ReLU mask of relu(bn(c) [+ residual]): kept as 1 bit per element (with a
             # residual it cannot be recomputed from c; without one it is what the fused data-gradient epilogue reads)
@@ -414,14 +422,20 @@ class ResNet18Encoder(nn.Module):
     def block_forward(self, x, pre, ds):
         """One BasicBlock: relu(bn2(conv2(relu(bn1(conv1(x))))) + identity), identity = x or
         bn(conv1x1/2(x)).  ``x`` NHWC bf16.  Returns (out, saved-for-backward)."""
-        idn, cd, std = x, None, None
+        idn, cd, std, idn_affine = x, None, None, None
         if ds:
             cd, accd = self._conv_fwd(x, f"{pre}.downsample.0")
-            idn, std = self._bn_fwd(cd, f"{pre}.downsample.1", False, acc=accd)
+            if self.training and self.fold_shortcut_norm:
+                # the shortcut's BatchNorm (no ReLU) is applied where it is consumed -- inside bn2's apply pass: one write
+                # and one read of a block-output-sized tensor less, bit-identical (the inner value is rounded as it was)
+                std = self._bn_affine(cd, f"{pre}.downsample.1", accd)
+                idn, idn_affine = cd, (std[2], std[3])
+            else:
+                idn, std = self._bn_fwd(cd, f"{pre}.downsample.1", False, acc=accd)
         c1, acc1 = self._conv_fwd(x, f"{pre}.conv1")
         a1, st1 = self._bn_fwd(c1, f"{pre}.bn1", True, acc=acc1)
         c2, acc2 = self._conv_fwd(a1, f"{pre}.conv2")
-        out, st2 = self._bn_fwd(c2, f"{pre}.bn2", True, residual=idn, acc=acc2)
+        out, st2 = self._bn_fwd(c2, f"{pre}.bn2", True, residual=idn, acc=acc2, residual_affine=idn_affine)
         return out, (x, c1, a1, st1, c2, out, st2, cd, std)
 
     def block_backward(self, g, pre, ds, saved):

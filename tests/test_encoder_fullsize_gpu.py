@@ -267,6 +267,15 @@ def test_training_step_is_bit_reproducible(images):
     enc.mask_identity_gradient = True
     diff = [k for k in g1 if not torch.equal(g1[k], g3[k])]
     assert not diff, f"masked identity-gradient join changes the gradients: {diff}"
+    # ... and the downsample shortcut's BatchNorm applied inside bn2's apply pass (isic_bn_apply_mask_res_affine_bf16: the inner
+    # value is rounded to bf16 as the pass that materialised it did) == the materialised shortcut: features, statistics, gradients
+    assert enc.fold_shortcut_norm
+    enc.fold_shortcut_norm = False
+    f4, s4, g4 = run()
+    enc.fold_shortcut_norm = True
+    assert torch.equal(f1, f4) and all(torch.equal(a, b) for a, b in zip(s1, s4))
+    diff = [k for k in g1 if not torch.equal(g1[k], g4[k])]
+    assert not diff, f"folding the shortcut's BatchNorm changes the gradients: {diff}"
 
 
 def _ref_block(x, P, stride, ds, forced=None):
