@@ -577,7 +577,12 @@ def run_gnn(args, world, rank, dev):
     gemm_fl = sum(2.0 * a[2] * a[3] * a[4] for a, _m in gemms)          # (transA, transB, M, N, K, ...)
     ms = sum(m for _n, _a, m in spmm)
     n_launch = len(spmm)
-    achieved = Gs * per_graph * batch_n / (batch_ms * 1e-3) / 1e9 if batch_ms > 0 else 0.0
+    # roofline.achieved = compulsory bytes of a launch / the launch duration measured INSIDE the step (HIP events around every
+    # aggregation launch of the eager pass of the same steps); the back-to-back micro-loop (one 25.7 MB input / output pair
+    # re-used by 120 launches: it sits in the 256 MB Infinity Cache) is kept as a labelled extra
+    in_step_ms = ms / max(n_launch, 1)
+    achieved = Gs * per_graph / (in_step_ms * 1e-3) / 1e9 if in_step_ms > 0 else 0.0
+    b2b = Gs * per_graph * batch_n / (batch_ms * 1e-3) / 1e9 if batch_ms > 0 else 0.0
     line = base_line("graphs/sec (GNN train step) @ 196-node k-NN patch graphs", "graphs/s",
                      world * Gs * args.steps / elapsed, world, args, elapsed, "f32")
     line["config"] = {"workload": WORKLOAD_GNN, "graphs_per_step_per_gpu": Gs, "nodes": N, "feat": D,
@@ -589,12 +594,14 @@ def run_gnn(args, world, rank, dev):
                                   "forward and transposed backward)",
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": pmc_traffic("gnn", graphs_per_step=Gs, nodes=N, hidden=F, knn_k=k),
-        "launches": batch_n, "avg_launch_ms": batch_ms / batch_n,
+        "launches": n_launch, "avg_launch_ms": in_step_ms,
         "algorithmic_bytes_per_launch": Gs * per_graph, "compulsory_bytes_per_layer_per_graph": per_graph,
-        "share_of_step_time": (batch_ms / batch_n) * 2 * L * args.steps * 1e-3 / elapsed,
-        "measured": f"HIP events around {reps} x {len(ops_)} back-to-back launches of the step's own aggregations "
-                    f"({L} forward, {L} transposed) on the launch stream, right after the timed region",
-        "in_step_launches": n_launch, "in_step_avg_launch_ms": ms / max(n_launch, 1), "in_step_measured": measured,
+        "share_of_step_time": in_step_ms * 2 * L * args.steps * 1e-3 / elapsed,
+        "measured": measured,
+        "back_to_back": {"achieved": b2b, "frac": b2b / HBM_PEAK_GBS, "launches": batch_n, "avg_launch_ms": batch_ms / batch_n,
+                         "measured": f"HIP events around {reps} x {len(ops_)} back-to-back launches of the step's own aggregations "
+                                     f"({L} forward, {L} transposed) on ONE input / output pair right after the timed region: "
+                                     f"a cache-resident best case, not the step"},
         # the step's largest kernel class next to it: every exact-fp32 GEMM launch of the step (v_mfma_f32_16x16x4_f32)
         "gemm_f32": {"bound": "mfma", "achieved": gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -369,4 +369,7 @@ def drop_args(drop):
         return 0, 1.0, 0, 0
     if drop.clock is not None:
         raise ValueError("registered ops take the dropout stream as a scalar; use a DropoutSpec without a device clock")
-    return int(drop.threshold), float(drop.scale), int(drop.seed), int(drop.stream)
+    # op schemas take signed 64-bit integers; seeds / streams are uint64 (a seed >= 2^63 is legal: torch.initial_seed() can be):
+    # pass the same 64 bits as a signed value -- ctypes turns it back into the unsigned one at the C ABI
+    s64 = lambda v: int(v) - (1 << 64) if int(v) >= (1 << 63) else int(v)
+    return int(drop.threshold), float(drop.scale), s64(drop.seed & 0xFFFFFFFFFFFFFFFF), s64(drop.stream & 0xFFFFFFFFFFFFFFFF)

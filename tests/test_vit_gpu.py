@@ -152,6 +152,47 @@ def test_gemm_f16_stats_writes_the_row_sums_of_its_rounded_output(M, N, K, res):
         assert float((Da.float() - Db.float()).abs().max()) <= 2.0 ** -9 * float(Da.float().abs().max()) + 1e-3
 
 
+@pytest.mark.parametrize("offset,spread,massive", [(50.0, 0.5, 0), (50.0, 0.5, 3), (-20.0, 2.0, 3), (0.0, 1.0, 4)])
+def test_folded_layernorm_on_rows_with_a_large_offset_and_massive_channels(offset, spread, massive):
+    """the folded LayerNorm takes the row variance as E[x^2] - mean^2 in fp32 from the producing product's (sum,
+    sum of squares) partials.  Random-init streams have mean ~ 1, std ~ 2; pretrained ViT residual streams carry rows with
+    |mean| >> std and a few channels 100x larger ("massive activations").  Such a stream (written by isic_gemm_f16_stats as a
+    pure residual) through the folded product, with the epilogue partials and with the two-pass statistics of
+    isic_row_stats_f16, against LayerNorm -> matmul in fp32: the partial-sum path must stay within the fp16 output tolerance
+    and within 3x the two-pass path's own error (fp32 cancellation: relative error of the variance ~ 1e-7 (1 + mean^2 / var))."""
+    from isic_hip.lib import call
+    M, N, NO = 777, 384, 256
+    g = torch.Generator().manual_seed(int(abs(offset)) + massive)
+    x = torch.randn(M, N, generator=g) * spread + offset + torch.randn(M, 1, generator=g) * spread
+    if massive:
+        cols = torch.randperm(N, generator=g)[:massive]
+        x[:, cols] = x[:, cols] * 100.0
+    x16 = x.to(F16)
+    A = torch.zeros(M, 64, dtype=F16, device=DEV)
+    W0 = torch.zeros(N, 64, dtype=F16, device=DEV)
+    b0 = torch.zeros(N, device=DEV)
+    C1 = torch.empty(M, N, device=DEV, dtype=F16)
+    parts = 2 * N // 128
+    st = torch.full((M, parts, 2), float("nan"), device=DEV)
+    call("isic_gemm_f16_stats", A, W0, b0, x16.to(DEV), C1, st, M, N, 64, 0, 0)          # C1 = the stream, st = its partial sums
+    assert torch.equal(C1.cpu().view(torch.int16), x16.view(torch.int16))
+    g2 = torch.Generator().manual_seed(5)
+    gamma, beta = torch.rand(N, generator=g2) + 0.5, torch.randn(N, generator=g2) * 0.2
+    W2 = (torch.randn(NO, N, generator=g2) / math.sqrt(N)).to(F16)
+    Wg, c, bb = _ln_fold(W2, gamma, beta, torch.zeros(NO))
+    ref = torch.nn.functional.layer_norm(x16.double(), (N,), gamma.double(), beta.double(), 1e-6) @ W2.double().t()
+    st2 = torch.empty(M, 2, device=DEV)
+    call("isic_row_stats_f16", C1, st2, M, N, 1e-6)
+    Da, Db = torch.empty(M, NO, device=DEV, dtype=F16), torch.empty(M, NO, device=DEV, dtype=F16)
+    call("isic_gemm_f16_ln", C1, Wg.to(DEV), bb.to(DEV), c.to(DEV), st2, 0, Da, M, NO, N, 0, 1e-6)
+    call("isic_gemm_f16_ln", C1, Wg.to(DEV), bb.to(DEV), c.to(DEV), st, parts, Db, M, NO, N, 0, 1e-6)
+    ea = float((Da.double().cpu() - ref).abs().max())
+    eb = float((Db.double().cpu() - ref).abs().max())
+    scale = float(ref.abs().max())
+    assert eb <= max(3.0 * ea, 4e-3 * scale), (offset, spread, massive, ea, eb, scale)
+    assert ea <= 4e-3 * scale + 4e-3, (ea, scale)
+
+
 @pytest.mark.parametrize("T,heads,n", [(196, 6, 3), (4, 6, 2), (50, 2, 5), (208, 1, 2), (17, 3, 1)])
 def test_attention_f16(T, heads, n):
     from isic_hip.lib import call
