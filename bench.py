@@ -1081,13 +1081,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--bags-per-step", type=int, default=32, help="mil: bags per optimizer step PER GPU")
+    ap.add_argument("--bags-per-step", type=int, default=64,
+                    help="mil: bags per optimizer step PER GPU (round 4: 64 = 4096 images of 224^2, every activation still "
+                         "resident (~45 GB); 32 / 48 / 64 bags per step: 851 / 880 / 894 bags/s on one box -- the persistent "
+                         "kernels' tails and the per-launch fixed costs are spread over more work; the pixel count of layer1, "
+                         "4096 x 56 x 56 = 12.8 M, has to stay below the 2^24 of the kernels' 40-bit reciprocal division)")
     ap.add_argument("--patches", type=int, default=64)
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--radiomics-dim", type=int, default=128)
-    ap.add_argument("--graphs-per-step", type=int, default=256, help="gnn: graphs per optimizer step PER GPU")
+    ap.add_argument("--graphs-per-step", type=int, default=668,
+                    help="gnn: graphs per optimizer step PER GPU (round 4: 668 x 196 nodes = 511.4 row tiles of 256 = two full "
+                         "rounds over the 256 CUs; a replayed step costs >= 4.8 us per dependent kernel whatever its size, and at "
+                         "256 graphs those fixed costs are a quarter of the step: 256 / 512 / 668 / 1024 graphs per step = 220 / "
+                         "258 / 275 / 275 k graphs/s on one box)")
     ap.add_argument("--images-per-step", type=int, default=2048, help="vit: images per forward PER GPU")
-    ap.add_argument("--teacher-bags-per-step", type=int, default=256, help="teacher: bags of 196 x 768 latents per step PER GPU")
+    ap.add_argument("--teacher-bags-per-step", type=int, default=668,
+                    help="teacher: bags of 196 x 768 latents per step PER GPU (as --graphs-per-step: 256 / 512 / 668 / 1024 = "
+                         "413 / 485 / 503 / 514 k bags/s)")
     ap.add_argument("--teacher-hidden", type=int, default=128)
     ap.add_argument("--teacher-att", type=int, default=64)
     ap.add_argument("--knn-graphs-per-step", type=int, default=2048, help="knn: images per adjacency-build step PER GPU")

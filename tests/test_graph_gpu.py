@@ -478,7 +478,7 @@ def test_graphmil_train_step_with_labels_fused_head_and_fallback(hidden):
 
 
 def test_graphmil_bench_geometry_whole_model_vs_oracle():
-    """The configs[3] step AT THE GEOMETRY bench.py TIMES -- 256 k-NN graphs of 196 nodes x 768 features per launch, 3-layer
+    """The configs[3] step AT THE GEOMETRY bench.py TIMES -- 668 k-NN graphs of 196 nodes x 768 features per launch, 3-layer
     GCN F = 128, 4 attention heads, light classifier, dropout 0.5 / 0.2 -- through the path the driver runs
     (GraphStore.batch_rows -> the input projection reading through the row index, the persistent / row-panel / A^T B fp32 GEMM
     kernels, GcnBlockFn, the fused head + loss, once eagerly and once as a replayed hipGraph with the device step clock) against
@@ -489,8 +489,8 @@ def test_graphmil_bench_geometry_whole_model_vs_oracle():
     from isic_hip.bags import BagOffsets
     from isic_hip.graph import knn_indices
     dev = torch.device(DEV)
-    Gs, N, D, F_, L, k, C = 256, 196, 768, 128, 3, 8, 7
-    n_graphs = 300
+    Gs, N, D, F_, L, k, C = 668, 196, 768, 128, 3, 8, 7        # bench.py's --graphs-per-step default
+    n_graphs = 700
     gen = torch.Generator().manual_seed(77)
     y = torch.arange(n_graphs) % C
     x = torch.randn(n_graphs, N, D, generator=gen) + 0.25 * y.view(-1, 1, 1).float()

@@ -265,8 +265,8 @@ def test_committed_pmc_traffic_profile_matches_the_kernels():
             f"SECTIONS={section} tools/collect_traffic.sh on the GPU box and commit profiles/r04_pmc_traffic.json")
         assert prof[section]["hbm_bytes_per_launch"] > 0
     # and bench.py's reader accepts it for the default workloads
-    assert bench.pmc_traffic("mil", bags_per_step=32, patches=64, image_size=224) > 0
-    assert bench.pmc_traffic("gnn", graphs_per_step=256, nodes=196, hidden=128, knn_k=8) > 0
+    assert bench.pmc_traffic("mil", bags_per_step=64, patches=64, image_size=224) > 0
+    assert bench.pmc_traffic("gnn", graphs_per_step=668, nodes=196, hidden=128, knn_k=8) > 0
     assert bench.pmc_traffic("vit", images_per_step=2048, image_size=224) > 0
 
 

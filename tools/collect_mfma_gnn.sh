@@ -2,7 +2,7 @@
 # MFMA utilisation and effective shader clock of the graph step's exact-fp32 GEMM kernels from rocprofv3 PMC counters (run on the
 # GPU box from the repo root; eager launch).  As tools/collect_mfma.sh: effective clock = GRBM_GUI_ACTIVE / 8 / kernel wall time;
 # SQ_VALU_MFMA_BUSY_CYCLES counts matrix-core busy cycles over all SIMDs (32 per v_mfma_f32_16x16x4_f32, 2048 FLOP each).
-# Output: gpurun_out/mfma/r03_pmc_mfma_gnn.json
+# Output: gpurun_out/mfma/r04_pmc_mfma_gnn.json
 set -e
 R=$PWD
 mkdir -p $R/gpurun_out/mfma
@@ -34,6 +34,6 @@ for g, a in agg.items():
               "mfma_busy_fraction": a["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0),
               "executed_f32_TFLOPs": a["SQ_VALU_MFMA_BUSY_CYCLES"] / 32.0 * 2048.0 / (a["ns"] * 1e-9) / 1e12}
 json.dump({"workload": "bench.py --config gnn (256 graphs x 196 nodes per step), eager launch, profiled pass", "kernels": out},
-          open("$R/gpurun_out/mfma/r03_pmc_mfma_gnn.json", "w"), indent=1)
+          open("$R/gpurun_out/mfma/r04_pmc_mfma_gnn.json", "w"), indent=1)
 print(json.dumps(out))
 PY

@@ -11,7 +11,7 @@
 #   SECTIONS="mil gnn vit" (default) selects what to re-collect; other sections of an existing file are kept.
 set -e
 R=$PWD
-B=${BAGS:-32}
+B=${BAGS:-64}
 SECTIONS=${SECTIONS:-"mil gnn vit"}
 OUT=$R/gpurun_out/traffic
 mkdir -p $OUT $R/profiles
@@ -42,7 +42,7 @@ except Exception:
 SPEC = {
     "mil": (("conv_igemm", "conv3x3_c64", "conv_halo", "conv_pgemm"), 35, "adam_step_kernel",
             {"bags_per_step": $B, "patches": 64, "image_size": 224}),
-    "gnn": (("spmm_",), None, "adam_step_kernel", {"graphs_per_step": 256, "nodes": 196, "hidden": 128, "knn_k": 8}),
+    "gnn": (("spmm_",), None, "adam_step_kernel", {"graphs_per_step": 668, "nodes": 196, "hidden": 128, "knn_k": 8}),
     "vit": (("gemm_f16_kernel",), None, None, {"images_per_step": 2048, "image_size": 224}),
 }
 for s in "$SECTIONS".split():
