@@ -37,7 +37,9 @@ int isic_test_conv2d_dgrad_pair_variant_bf16(const uint16_t* dy, const uint16_t*
 /* isic_conv2d_wgrad_bf16 (same arguments) with `variant` bits: 0 = shipped; 16 = the 32-output-channel all-taps kernel
  * (conv_wgrad_c128.hip) where the 64-channel one (conv_wgrad_c128b.hip) ships; on that kernel: 1 = the block order it does
  * NOT ship with (XCD-grouped co-slice blocks vs pair-major), 2 / 4 / 8 = MFMAs / fragment reads / LDS-DMA compiled out
- * (timing ablations: the results are garbage). */
+ * (timing ablations: the results are garbage).  Stride-2 3x3 layers: 16 = the per-tap kernel (conv_wgrad.hip) where the
+ * all-taps strided kernel (conv_wgrad_s2.hip) ships, 32 = the all-taps strided kernel also where the per-tap one ships
+ * (more than four (64 ci, 128 co) pairs). */
 int isic_test_conv2d_wgrad_variant_bf16(const uint16_t* x, const uint16_t* dy, float* dw, int N, int Hin, int Win, int Cin,
                                         int Hout, int Wout, int Cout, int Kh, int Kw, int stride, int pad, void* workspace,
                                         size_t workspace_bytes, int variant, void* stream);

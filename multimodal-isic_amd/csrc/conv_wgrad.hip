@@ -292,6 +292,11 @@ size_t isic_wgrad_c128b_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int isic_wgrad_c128b_launch(const uint16_t* x, const uint16_t* dy, float* dw, int N, int H, int W, int Cin, int Cout,
                             void* workspace, int ablation, hipStream_t stream);
 
+// ... and of the 3x3 / stride 2 / pad 1 layers with Cin % 64 == 0, Cout % 128 == 0 (conv_wgrad_s2.hip)
+size_t isic_wgrad_s2_workspace_bytes(int N, int Hi, int Wi, int Cin, int Cout);
+int isic_wgrad_s2_launch(const uint16_t* x, const uint16_t* dy, float* dw, int N, int Hi, int Wi, int Cin, int Cout,
+                         void* workspace, hipStream_t stream);
+
 namespace {
 // the all-taps kernels are always used for the shapes they cover (no environment switches, no global state)
 inline bool wgrad_c128_enabled() { return true; }
@@ -321,6 +326,10 @@ size_t isic_conv2d_wgrad_workspace_bytes(int N, int Cin, int Hout, int Wout, int
     const size_t c128b = isic_wgrad_c128b_workspace_bytes(N, Hout, Wout, Cin, Cout);
     if (c128b > need) need = c128b;
   }
+  if (Cin % 64 == 0 && Cout % 128 == 0 && Kh == 3 && Kw == 3) {   // the stride is not an argument: as if it were 2
+    const size_t s2 = isic_wgrad_s2_workspace_bytes(N, 2 * Hout, 2 * Wout, Cin, Cout);
+    if (s2 > need) need = s2;
+  }
   return need;
 }
 
@@ -343,7 +352,7 @@ int isic_test_conv2d_wgrad_variant_bf16(const uint16_t* x, const uint16_t* dy, f
 namespace {
 
 // variant (include/isic_hip_test.h): 0 = shipped; bit 4 (16) = the 32-output-channel all-taps kernel where the 64-channel
-// one ships; bit 0 = that kernel with the OTHER block order; bits 1-3 = its compiled-out parts (timing ablations)
+// one ships, the per-tap kernel where the strided all-taps one ships; bit 0 = that kernel with the OTHER block order; bits 1-3 = its compiled-out parts (timing ablations)
 int conv2d_wgrad_dispatch(const uint16_t* x, const uint16_t* dy, float* dw, int N, int Hin, int Win, int Cin,
                           int Hout, int Wout, int Cout, int Kh, int Kw, int stride, int pad, void* workspace,
                           size_t workspace_bytes, int variant, void* stream) {
@@ -379,6 +388,18 @@ int conv2d_wgrad_dispatch(const uint16_t* x, const uint16_t* dy, float* dw, int 
       if (workspace_bytes < need) return ISIC_ERR_WORKSPACE;
       const int rc = isic_wgrad_c128_launch(x, dy, dw, N, Hin, Win, Cin, Cout, workspace, (kWgradC128XcdGroup ^ (variant & 1)) | (variant & 14),
                                             as_stream(stream));
+      return rc != ISIC_OK ? rc : isic_launch_status();
+    }
+  }
+  // the input staged once per tile instead of once per tap: 1.42 -> 0.71 ms for 64 -> 128 @ 56x56 and 0.76 -> 0.70 ms for
+  // 128 -> 256 @ 28x28 at 4096 images; with 16 (64 ci, 128 co) pairs re-staging each other's operands (256 -> 512 @ 14x14)
+  // it loses, 0.75 against 0.69 ms, and the per-tap kernel stays (variant bit 5 forces it on there: tools/halo_ab.py)
+  if (Cin % 64 == 0 && Cout % 128 == 0 && Kh == 3 && Kw == 3 && stride == 2 && pad == 1 && Hin == 2 * Hout && Win == 2 * Wout &&
+      !(variant & 16) && ((Cin / 64) * (Cout / 128) <= 4 || (variant & 32))) {
+    const size_t need = isic_wgrad_s2_workspace_bytes(N, Hin, Win, Cin, Cout);
+    if (need != 0) {
+      if (workspace_bytes < need) return ISIC_ERR_WORKSPACE;
+      const int rc = isic_wgrad_s2_launch(x, dy, dw, N, Hin, Win, Cin, Cout, workspace, as_stream(stream));
       return rc != ISIC_OK ? rc : isic_launch_status();
     }
   }

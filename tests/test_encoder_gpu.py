@@ -466,6 +466,45 @@ def test_conv_wgrad_all_taps_channel_slices_and_packed_images(case):
     assert torch.equal(dw2 - 1.0, (got + 1.0) - 1.0)
 
 
+@pytest.mark.parametrize("case", [(3, 56, 56, 64, 128), (40, 56, 56, 64, 128), (5, 28, 28, 128, 256), (7, 14, 14, 256, 512),
+                                  (2, 20, 72, 64, 128), (3, 10, 26, 128, 128), (9, 6, 14, 64, 256), (1, 2, 2, 64, 128)])
+def test_conv_wgrad_strided_all_taps_kernel(case):
+    """Weight gradient of the 3x3 / stride 2 / pad 1 layers (conv_wgrad_s2.hip: the input staged once per tile as odd / even
+    column planes; ResNet-18 layer2.0 / 3.0 / 4.0 conv1) against an fp64 reference built from nine strided matrix products:
+    one and many tiles per block, packed 14- and 7-wide outputs with odd image counts, output widths above 32 that tile,
+    several channel slices; deterministic (no atomics), accumulates into the caller's gradient, and agrees with the
+    per-tap kernel it replaces."""
+    from isic_hip.lib import call
+    N, H, W, Ci, Co = case
+    Ho, Wo = H // 2, W // 2
+    g = torch.Generator().manual_seed(29)
+    x = torch.randn(N, H, W, Ci, generator=g).to(DEV).to(BF)
+    dy = torch.randn(N, Ho, Wo, Co, generator=g).to(DEV).to(BF)
+    ws = torch.empty(call("isic_conv2d_wgrad_workspace_bytes", N, Ci, Ho, Wo, Co, 3, 3), device=DEV, dtype=torch.uint8)
+
+    def run(variant=0):
+        dw = torch.zeros(Co, 3, 3, Ci, device=DEV)                       # [co][kh][kw][ci]
+        call("isic_test_conv2d_wgrad_variant_bf16", x, dy, dw, N, H, W, Ci, Ho, Wo, Co, 3, 3, 2, 1, ws, ws.numel(), variant)
+        torch.cuda.synchronize()
+        return dw
+
+    got = run(32)                                # 32: the all-taps kernel also where the dispatch prefers the per-tap one
+    xp = F.pad(x.double(), (0, 0, 1, 1, 1, 1))
+    dyd = dy.double().reshape(-1, Co)
+    ref = torch.empty(Co, 3, 3, Ci, device=DEV, dtype=torch.float64)
+    for kh in range(3):
+        for kw in range(3):
+            ref[:, kh, kw, :] = dyd.t() @ xp[:, kh:kh + 2 * Ho:2, kw:kw + 2 * Wo:2, :].reshape(-1, Ci)
+    tol = dict(rtol=2e-5, atol=1e-6 * float(ref.abs().max().cpu()) + 1e-6)
+    assert_close(got.cpu(), ref.cpu(), what=f"strided wgrad {case}", **tol)
+    assert_close(run(16).cpu(), ref.cpu(), what=f"per-tap strided wgrad {case}", **tol)
+    assert torch.equal(got, run(32)), "the strided all-taps weight gradient must be reproducible run to run"
+    dw2 = torch.ones(Co, 3, 3, Ci, device=DEV)
+    call("isic_test_conv2d_wgrad_variant_bf16", x, dy, dw2, N, H, W, Ci, Ho, Wo, Co, 3, 3, 2, 1, ws, ws.numel(), 32)
+    assert torch.equal(dw2 - 1.0, (got + 1.0) - 1.0)
+    assert_close(run(0).cpu(), ref.cpu(), what=f"shipped strided wgrad {case}", **tol)
+
+
 @pytest.mark.parametrize("shape", [(2, 12, 12), (3, 9, 13), (2, 112, 112)])
 def test_stem_fused_bn_relu_maxpool_and_pooled_bn_backward(shape):
     """The stem fusions are bit-identical to the kernels they replace: bn_apply(+ReLU) -> maxpool forward, and

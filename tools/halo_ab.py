@@ -85,6 +85,29 @@ def wgrad_ab(a):
             print(f"{name} wgrad variant {v:2d}: {t:7.4f} ms  {gf / t:7.0f} TF/s  {same}", flush=True)
 
 
+def wgrad_s2_ab(a):
+    """the strided all-taps weight gradient (variant 0) against the per-tap kernel it replaces (variant 16)"""
+    N = a.n
+    for name, C, Co, H in (("l2.0", 64, 128, 56), ("l3.0", 128, 256, 28), ("l4.0", 256, 512, 14)):
+        Ho = H // 2
+        x = torch.randn(N, H, H, C, device=DEV).to(BF)
+        dy = torch.randn(N, Ho, Ho, Co, device=DEV).to(BF)
+        gf = 2.0 * N * Ho * Ho * Co * C * 9 / 1e9
+        wsb = torch.empty(call("isic_conv2d_wgrad_workspace_bytes", N, C, Ho, Ho, Co, 3, 3), device=DEV, dtype=torch.uint8)
+        variants = [32, 16]                          # 32: the all-taps kernel whatever the channel counts
+        dws = [torch.zeros(Co, C, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last) for _ in variants]
+        fns = [(lambda v=v, dw=dw: call("isic_test_conv2d_wgrad_variant_bf16", x, dy, dw, N, H, H, C, Ho, Ho, Co, 3, 3, 2, 1, wsb,
+                                        wsb.numel(), v)) for v, dw in zip(variants, dws)]
+        for f in fns:
+            f()
+        torch.cuda.synchronize()
+        ref = float(dws[1].abs().max())
+        ts = interleaved(fns, a.iters)
+        for v, dw, t in zip(variants, dws, ts):
+            print(f"{name} strided wgrad variant {v:2d}: {t:7.4f} ms  {gf / t:7.0f} TF/s  max |diff| / max "
+                  f"{float((dw - dws[1]).abs().max()) / ref:.2e}", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=2048)
@@ -93,8 +116,11 @@ def main():
     ap.add_argument("--layers", default="l2,l3,l4")
     ap.add_argument("--addend", action="store_true", help="also the data gradient with a residual-gradient addend")
     ap.add_argument("--pair", action="store_true", help="A/B of the downsample-block pair data gradient: variants 0 and 2000")
+    ap.add_argument("--wgrad-s2", action="store_true", help="the strided all-taps weight gradient against the per-tap kernel")
     ap.add_argument("--wgrad", action="store_true", help="A/B of the weight-gradient block orders instead (isic_test_conv2d_wgrad_variant_bf16)")
     a = ap.parse_args()
+    if a.wgrad_s2:
+        return wgrad_s2_ab(a)
     if a.wgrad:
         return wgrad_ab(a)
     if a.pair:

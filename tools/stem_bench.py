@@ -43,7 +43,11 @@ def main():
     dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     gb_full, gb_pool = y0.numel() * 2 / 1e9, p.numel() * 2 / 1e9
     wsp = torch.empty(call("isic_conv_stem_wgrad_workspace_bytes"), device=DEV, dtype=torch.uint8)
+    wst = torch.randn(64, 7, 8, 4, device=DEV).to(BF)
+    st = torch.zeros(2, 64, C, device=DEV, dtype=torch.float64)
     rows = [
+        ("stem conv fwd + BatchNorm sums", gb_full + x4.numel() * 2 / 1e9,
+         lambda: call("isic_conv_stem_fwd_stats_bf16", x4, wst, dy, N, H, W, Ho, Wo, st[0], st[1], 64)),
         ("bn+relu+maxpool fwd (+argmax, +x_sel)", gb_full + 2.5 * gb_pool,
          lambda: call("isic_bn_relu_maxpool3x3s2_fwd_sel_bf16", y0, scale, shift, p, am, xs, N, Ho, Wo, C, Hp, Wp)),
         ("bn bwd sums, full-size (old)", gb_full + 1.5 * gb_pool,
