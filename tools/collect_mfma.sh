@@ -19,6 +19,7 @@ def group(k):
     if "conv_igemm" in k: return "conv_igemm (generic: data gradients with 64 outputs, 1x1 data gradients)"
     if "conv3x3_c64" in k: return "conv3x3_c64p (64->64 forward / data gradient)"
     if "wgrad_c64_kernel" in k: return "wgrad_c64 (64->64 weight gradient)"
+    if "wgrad_s2_kernel" in k: return "wgrad_s2 (stride-2 3x3 weight gradients, input staged once per tile)"
     if "wgrad_c128b_kernel" in k: return "wgrad_c128b (>=128-channel 3x3 weight gradients, 64 output channels per block)"
     if "wgrad_c128_kernel" in k: return "wgrad_c128 (128->128 weight gradient, 32 output channels per block)"
     if "conv_wgrad_kernel" in k: return "conv_wgrad (other weight gradients)"
