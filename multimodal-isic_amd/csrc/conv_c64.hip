@@ -288,11 +288,19 @@ __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsig
 }
 // (the s_nop covers the hazard "VMEM store of more than 64 bits followed by a write of its data VGPRs", which the
 //  compiler cannot see through the asm statement)
+// NT = false (shipped since late round 4): ordinary stores.  The two waves of a SIMD write the two 64-byte halves of a pixel
+// row half a tile apart; non-temporal, each half goes to memory by itself (64-byte segments stream at 3.2 TB/s against 5.4
+// for whole lines, profiles/r03_probe_rw.txt), cached, the L2 joins them: dgrad + addend 1.356 -> 1.295 ms, dgrad 0.951 ->
+// 0.939 ms, forward with statistics unchanged (tools/halo_ab.py --layers l1 --exps 0,1, 4096 images).
+template <bool NT = false>
 __device__ __forceinline__ void store16_s(void* sbase, unsigned voff, u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+  if (NT) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
+template <bool NT = false>
 __device__ __forceinline__ void store16_v(void* ptr, u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+  if (NT) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
 }
 
 // ABL (test entry only; results are garbage): bit 0 = no MFMAs, bit 1 = no fragment reads, bit 2 = no LDS-DMA, bit 3 = no stores
@@ -455,9 +463,9 @@ __global__ __launch_bounds__(512) void conv3x3_c64p_kernel(C64PArgs a) {
       }
       // exactly one store per M-tile is ISSUED whatever the validity (see CNT_TOP)
       if (ABL & 8) { asm volatile("" :: "v"(v)); }
-      else if (seg == 0) store16_s(a.out + off, lane_out, v);
-      else if (seg == 1) store16_s(g_c64_sink, (unsigned)lane * 16, v);
-      else store16_v(valid ? (void*)(reinterpret_cast<unsigned char*>(a.out + off) + lane_out) : (void*)(g_c64_sink + lane * 16), v);
+      else if (seg == 0) store16_s<(ABL & 16) != 0>(a.out + off, lane_out, v);
+      else if (seg == 1) store16_s<(ABL & 16) != 0>(g_c64_sink, (unsigned)lane * 16, v);
+      else store16_v<(ABL & 16) != 0>(valid ? (void*)(reinterpret_cast<unsigned char*>(a.out + off) + lane_out) : (void*)(g_c64_sink + lane * 16), v);
     }
   };
 
@@ -574,6 +582,11 @@ int isic_conv3x3_c64_launch(int variant, const uint16_t* in, const uint16_t* w, 
     a.total_tiles = (int)blocks;
     a.tiles_per_block = ceil_div(a.total_tiles, cus);
     const int grid = ceil_div(a.total_tiles, a.tiles_per_block);       // every block owns at least one tile
+    if (experiment == 1) {                                 // A/B: the non-temporal stores of rounds 2-3 instead of ordinary ones
+      if (stat_sum) return launch_c64p<true, false, 16>(a, grid, stream);
+      if (addend) return launch_c64p<false, true, 16>(a, grid, stream);
+      return launch_c64p<false, false, 16>(a, grid, stream);
+    }
     if (experiment >= 2) {                                 // timing ablations: experiment digit e -> where the time goes
       if (stat_sum || addend) return ISIC_ERR_UNSUPPORTED;
       switch (experiment) {
