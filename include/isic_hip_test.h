@@ -22,6 +22,8 @@ extern "C" {
  *            0 shipped default, 1 never, 2 wherever the kernel supports the shape (Cout % 128 == 0)
  *   ten-thousands  conv_halo.hip: 0 = shipped K loop (one barrier per two K-tiles where Cin % 128 == 0), 1 = the round-3 loop
  *            (one barrier per K-tile, three weight stages); same products in the same order: bit-equal (tools/halo_ab.py)
+ *            conv_c64.hip (persistent kernel): 1 = the non-temporal output stores of rounds 2-3 instead of ordinary ones (bit-equal);
+ *            2..7 on either kernel = parts compiled out (timing ablations: the results are garbage)
  * variant = 0 is exactly isic_conv2d_igemm_bf16. */
 int isic_test_conv2d_igemm_variant_bf16(const uint16_t* in, const uint16_t* w, uint16_t* out, int N, int Hin, int Win,
                                         int Cin, int Hout, int Wout, int Cout, int Kh, int Kw, int up, int down, int pad,
